@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (container only).
+
+TEST INFRASTRUCTURE.  Imports the reference from /root/reference through
+oracle/refload.py (load-time py2->py3 transform, nothing copied to disk) and
+records its outputs on seeded synthetic inputs made by
+fluorosequencingimageanalysis_amd/synth.py.  The .npz files hold DATA only
+(inputs or their seeds + the reference's outputs).
+
+Usage (about 4 minutes on 8 cores):
+  NPY_DISABLE_CPU_FEATURES="AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL AVX512_SPR" \
+      python oracle/gen_golden.py [--only fields|reg|kat]
+
+Golden sets: G1 per-ROI fits, G2 candidate lists, G3 full
+find_peptides tables, G4 phase_correlate tuples, G5 known-answer tests.
+"""
+import argparse
+import multiprocessing as mp
+import os
+import sys
+import zlib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+NPY_ENV = "AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL AVX512_SPR"
+if __name__ == "__main__" and os.environ.get("NPY_DISABLE_CPU_FEATURES") != NPY_ENV:
+    os.environ["NPY_DISABLE_CPU_FEATURES"] = NPY_ENV      # numpy.exp/sin/cos == glibc's
+    os.execv(sys.executable, [sys.executable] + sys.argv)
+
+import numpy as np  # noqa: E402
+
+from fluorosequencingimageanalysis_amd import synth  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+# name -> (kind, args)   every field is rebuilt from these seeds by tests
+FIELDS = {
+    "f0_cfg1_512_200": dict(seed=1, shape=(512, 512), n_spots=200, kind="std"),
+    "f1_cfg2_512_500": dict(seed=0, shape=(512, 512), n_spots=500, kind="std"),
+    "f2_rect_384x640_300": dict(seed=7, shape=(384, 640), n_spots=300, kind="std"),
+    "f3_hard_256": dict(seed=11, shape=(256, 256), n_spots=150, kind="hard"),
+    "f4_dense_1024_1250": dict(seed=5, shape=(1024, 1024), n_spots=1250, kind="std"),
+    "f5_small_96": dict(seed=21, shape=(96, 96), n_spots=12, kind="std"),
+}
+
+
+def build_field(spec):
+    if spec["kind"] == "std":
+        return synth.make_field(spec["seed"], spec["shape"], spec["n_spots"])
+    # "hard": spots anywhere (also on the borders), overlapping, some saturating
+    rng = np.random.default_rng([spec["seed"], 0xBAD])
+    H, W = spec["shape"]
+    n = spec["n_spots"]
+    r = rng.uniform(0.5, H - 0.5, n)
+    c = rng.uniform(0.5, W - 0.5, n)
+    a = 10 ** rng.uniform(2.5, 4.9, n)
+    return synth.render(spec["shape"], r, c, a, spec["seed"])
+
+
+_R = None
+
+
+def _ref():
+    global _R
+    if _R is None:
+        from refload import load_reference
+        _R = load_reference()
+        holder = []
+
+        class Rec(_R.mp.mpfit):
+            def __init__(self, *a, **k):
+                _R.mp.mpfit.__init__(self, *a, **k)
+                holder.append(self)
+        _R.gf.mpfit = Rec
+        _R.holder = holder
+    return _R
+
+
+class _NoisyNumpy:
+    """numpy proxy whose exp() is perturbed by a seeded +-1 ulp (stability probe)."""
+
+    def __init__(self, seed):
+        self._rng = np.random.default_rng(seed)
+
+    def __getattr__(self, k):
+        return getattr(np, k)
+
+    def exp(self, x):
+        y = np.exp(x)
+        d = self._rng.integers(-1, 2, size=np.shape(y))
+        return np.where(d > 0, np.nextafter(y, np.inf), np.where(d < 0, np.nextafter(y, -np.inf), y))
+
+
+def fit_chunk(args):
+    """Fit a chunk of ROIs with the reference; returns per-ROI records."""
+    rois, noise_seed = args
+    R = _ref()
+    R.gf.numpy = _NoisyNumpy(noise_seed) if noise_seed is not None else np
+    out = []
+    for roi in rois:
+        del R.holder[:]
+        res = R.pf._fit_2d_gaussian(roi.astype(np.int64))
+        m = R.holder[-1]
+        # returned order (h_0,w_0,H,A,sh,sw,theta,fit) ; mpfit order p = (H,A,p2,p3,s4,s5,th)
+        out.append((np.array(m.params, dtype=np.float64), int(m.status), int(m.niter),
+                    int(m.nfev), float(m.fnorm), np.asarray(res[7], dtype=np.float64)))
+    R.gf.numpy = np
+    return out
+
+
+def run_fits(pool, rois, noise_seed=None, chunk=64):
+    chunks = [(rois[i:i + chunk], None if noise_seed is None else noise_seed * 100003 + i)
+              for i in range(0, len(rois), chunk)]
+    res = []
+    for part in pool.imap(fit_chunk, chunks):
+        res.extend(part)
+    return res
+
+
+def gen_fields(pool, with_stability=("f0_cfg1_512_200", "f1_cfg2_512_500", "f3_hard_256")):
+    R = _ref()
+    for name, spec in FIELDS.items():
+        img = build_field(spec)
+        cands = R.pf._psf_candidates(img)
+        cand = np.array(cands, dtype=np.int32).reshape(-1, 2)
+        rois = [img[h - 2:h + 3, w - 2:w + 3] for h, w in cands]
+        print(name, img.shape, "candidates", len(cands), flush=True)
+        fits = run_fits(pool, rois)
+        params = np.array([f[0] for f in fits]).reshape(-1, 7)
+        status = np.array([f[1] for f in fits], dtype=np.int32)
+        niter = np.array([f[2] for f in fits], dtype=np.int32)
+        nfev = np.array([f[3] for f in fits], dtype=np.int32)
+        fnorm = np.array([f[4] for f in fits])
+        # replay the cached fits through the reference's own find_peptides
+        it = iter(fits)
+        roi_it = iter(rois)
+
+        def replay(sub, implementation='agpy'):
+            f = next(it)
+            r = next(roi_it)
+            assert np.array_equal(sub, r)
+            p = f[0]
+            return (p[2], p[3], p[0], p[1], p[4], p[5], p[6], f[5])
+        orig = R.pf._fit_2d_gaussian
+        R.pf._fit_2d_gaussian = replay
+        try:
+            table = R.pf.find_peptides(img)
+        finally:
+            R.pf._fit_2d_gaussian = orig
+        keys = np.array(list(table.keys()), dtype=np.int32).reshape(-1, 2)
+        vals = list(table.values())
+        tab7 = np.array([[float(x) for x in v[:7]] for v in vals]).reshape(-1, 7)
+        tab_sub = np.array([v[7] for v in vals], dtype=np.int64).reshape(-1, 5, 5)
+        tab_fit = np.array([v[8] for v in vals], dtype=np.float64).reshape(-1, 5, 5)
+        tab_m = np.array([[float(v[9]), float(v[10]), float(v[11])] for v in vals]).reshape(-1, 3)
+        extra = {}
+        if name in with_stability:
+            stable = np.ones(len(fits), dtype=bool)
+            for k in (1, 2):
+                alt = run_fits(pool, rois, noise_seed=k)
+                ap = np.array([f[0] for f in alt]).reshape(-1, 7)
+                ast = np.array([f[1] for f in alt], dtype=np.int32)
+                rel = np.abs(ap[:, :6] - params[:, :6]) / np.maximum(np.abs(params[:, :6]), 1e-300)
+                stable &= (rel.max(axis=1) <= 1e-6) & (ast == status)
+            extra["stable"] = stable
+            print("   stable fraction", stable.mean(), flush=True)
+        np.savez_compressed(
+            os.path.join(GOLD, "field_%s.npz" % name),
+            seed=spec["seed"], shape=np.array(spec["shape"]), n_spots=spec["n_spots"],
+            kind=spec["kind"], image_crc=np.uint32(zlib.crc32(img.tobytes())),
+            image=img if img.size <= 256 * 256 else np.zeros((0, 0), np.uint16),
+            candidates=cand, params=params, status=status, niter=niter, nfev=nfev, fnorm=fnorm,
+            table_keys=keys, table7=tab7, table_sub=tab_sub, table_fit=tab_fit, table_metrics=tab_m,
+            **extra)
+        print("   peaks", len(keys), "status mix", np.unique(status, return_counts=True), flush=True)
+
+
+def gen_reg():
+    R = _ref()
+    rng = np.random.default_rng(99)
+    cases = []
+    frames, off = synth.make_cycle_stack(3, n_cycles=5, shape=(512, 512), n_spots=500)
+    for k in range(1, 5):
+        cases.append(("cycle512_%d" % k, frames[k - 1], frames[k]))
+    frames, off = synth.make_cycle_stack(4, n_cycles=4, shape=(200, 328), n_spots=150)
+    for k in range(1, 4):
+        cases.append(("cycle200x328_%d" % k, frames[k - 1], frames[k]))
+    # odd sizes, negative / large shifts of smooth random content
+    for i, (H, W, dy, dx) in enumerate([(63, 65, -3, 5), (101, 77, 7, -11), (64, 64, 0, 0),
+                                        (33, 128, -16, 40), (127, 31, 20, -9), (50, 50, -25, 25),
+                                        (97, 97, 12.4, -7.7), (81, 120, -0.35, 0.65), (16, 16, 1, 1)]):
+        base = rng.normal(0, 1, (H + 64, W + 96))
+        from scipy.ndimage import gaussian_filter, shift as ndshift
+        base = gaussian_filter(base, 2.0) * 1000 + 500
+        ref = base[32:32 + H, 48:48 + W]
+        mov = ndshift(base, (dy, dx), order=3, mode="wrap")[32:32 + H, 48:48 + W]
+        ref = np.clip(np.rint(ref), 0, 65535).astype(np.uint16)
+        mov = np.clip(np.rint(mov + rng.normal(0, 2, mov.shape)), 0, 65535).astype(np.uint16)
+        cases.append(("odd%d_%dx%d" % (i, H, W), ref, mov))
+    out = {}
+    names = []
+    for name, a, b in cases:
+        names.append(name)
+        out["ref_" + name] = a
+        out["reg_" + name] = b
+        for uf in (1, 20, 100):
+            r = R.pc.phase_correlate(a, b, upsample_factor=uf)
+            out["out_%s_uf%d" % (name, uf)] = np.array([float(np.real(x)) for x in r])
+            print(name, uf, out["out_%s_uf%d" % (name, uf)], flush=True)
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(GOLD, "registration.npz"), **out)
+
+
+def gen_kat():
+    R = _ref()
+    out = {}
+    # qrfac worked example of the reference docstring (mpfit.py:1711-1742), run through the code
+    m = R.mp.mpfit.__new__(R.mp.mpfit)
+    m.debug = 0
+    m.machar = R.mp.machar(double=1)
+    a = np.array([[9., 4.], [2., 8.], [6., 7.]])
+    aa, ipvt, rdiag, acnorm = m.qrfac(a.copy(), pivot=0)
+    out["qrfac_in"], out["qrfac_a"], out["qrfac_ipvt"] = a, aa, ipvt
+    out["qrfac_rdiag"], out["qrfac_acnorm"] = rdiag, acnorm
+    rng = np.random.default_rng(5)
+    J = rng.normal(0, 1, (25, 7)) * 10 ** rng.uniform(-2, 3, 7)
+    aa, ipvt, rdiag, acnorm = m.qrfac(J.copy(), pivot=1)
+    out["qrfac25_in"], out["qrfac25_a"], out["qrfac25_ipvt"] = J, aa, ipvt
+    out["qrfac25_rdiag"], out["qrfac25_acnorm"] = rdiag, acnorm
+    # enorm pins (numpy.dot through this container's OpenBLAS) : contiguous 25/7, strided columns
+    vec25 = rng.normal(0, 1, (64, 25)) * 10 ** rng.uniform(-3, 3, (64, 1))
+    vec7 = rng.normal(0, 1, (64, 7)) * 10 ** rng.uniform(-3, 3, (64, 1))
+    out["enorm25_in"], out["enorm25_out"] = vec25, np.array([m.enorm(v) for v in vec25])
+    out["enorm7_in"], out["enorm7_out"] = vec7, np.array([m.enorm(v) for v in vec7])
+    out["enorm_col_in"] = J
+    out["enorm_col_out"] = np.array([[m.enorm(J[j:, k]) for k in range(7)] for j in range(8)])
+    # epoch hash round trips (pflib.py:523-566)
+    epochs = np.array([0.4, 1.0, 35.0, 36.0, 1296.0, 1450000000.0, 1791084336.2, 2 ** 40 + 0.5])
+    out["epochs"] = epochs
+    out["epoch_hashes"] = np.array([R.pf._epoch_to_hash(e) for e in epochs])
+    out["hash_epochs"] = np.array([R.pf._hash_to_epoch(h) for h in out["epoch_hashes"]], dtype=np.int64)
+    # illumina_s_n (pflib.py:261-281)
+    rois = rng.integers(50, 4000, (32, 5, 5)).astype(np.int64)
+    out["sn_in"] = rois
+    out["sn_out"] = np.array([R.pf.illumina_s_n(r) for r in rois])
+    # twodgaussian model values (gaussfitter.py:63-140)
+    P = np.column_stack([rng.uniform(0, 200, 64), rng.uniform(100, 3000, 64), rng.uniform(2, 3, 64),
+                         rng.uniform(2, 3, 64), rng.uniform(.75, 2, 64), rng.uniform(.75, 2, 64),
+                         rng.uniform(0, 360, 64)])
+    P[:8, 6] = 0.0
+    P[8:12, 6] = 360.0
+    out["model_in"] = P
+    out["model_out"] = np.array([R.gf.twodgaussian(p, 0, 1, 1)(*np.indices((5, 5))) for p in P])
+    np.savez_compressed(os.path.join(GOLD, "kat.npz"), **out)
+    print("kat done", flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--procs", type=int, default=8)
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    if a.only in ("", "kat"):
+        gen_kat()
+    if a.only in ("", "reg"):
+        gen_reg()
+    if a.only in ("", "fields"):
+        with mp.Pool(a.procs) as pool:
+            gen_fields(pool)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,124 @@
+"""ctypes wrapper of the CPU oracle (TEST INFRASTRUCTURE - never imported by the product)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class FsqOFit(ctypes.Structure):
+    _fields_ = [("p", ctypes.c_double * 7), ("fnorm", ctypes.c_double),
+                ("status", ctypes.c_int32), ("niter", ctypes.c_int32),
+                ("nfev", ctypes.c_int32), ("pad", ctypes.c_int32)]
+
+
+class FsqORow(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_double) for k in
+                ("h0", "w0", "H", "A", "sigma_h", "sigma_w", "theta", "rmse", "r2", "s_n")] + \
+               [("h", ctypes.c_int32), ("w", ctypes.c_int32)]
+
+
+FIT_DTYPE = np.dtype([("p", np.float64, 7), ("fnorm", np.float64), ("status", np.int32),
+                      ("niter", np.int32), ("nfev", np.int32), ("pad", np.int32)])
+ROW_DTYPE = np.dtype([(k, np.float64) for k in
+                      ("h0", "w0", "H", "A", "sigma_h", "sigma_w", "theta", "rmse", "r2", "s_n")] +
+                     [("h", np.int32), ("w", np.int32)])
+assert FIT_DTYPE.itemsize == ctypes.sizeof(FsqOFit) and ROW_DTYPE.itemsize == ctypes.sizeof(FsqORow)
+
+DEFAULT_K = np.array([[-5935, -5935, -5935, -5935, -5935],
+                      [-5935, 8027, 8027, 8027, -5935],
+                      [-5935, 8027, 30742, 8027, -5935],
+                      [-5935, 8027, 8027, 8027, -5935],
+                      [-5935, -5935, -5935, -5935, -5935]], dtype=np.int64)
+
+_libs = {}
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HERE])
+
+
+def lib(libm=False):
+    name = "libfsq_oracle_libm.so" if libm else "libfsq_oracle.so"
+    if name not in _libs:
+        path = os.path.join(HERE, name)
+        if not os.path.exists(path):
+            build()
+        L = ctypes.CDLL(path)
+        L.fsq_o_illumina_s_n.restype = ctypes.c_double
+        L.fsq_o_enorm.restype = ctypes.c_double
+        L.fsq_o_pairwise_sum.restype = ctypes.c_double
+        L.fsq_o_pairwise_sum.argtypes = [ctypes.c_void_p, ctypes.c_long]
+        _libs[name] = L
+    return _libs[name]
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def candidates(img, med_size=5, K=DEFAULT_K, c_std=2.0, libm=False, return_cm=False):
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    K = np.ascontiguousarray(K, dtype=np.int64)
+    H, W = img.shape
+    cap = H * W
+    hw = np.empty((cap, 2), np.int32)
+    cm = np.empty((H, W), np.int64)
+    thr = ctypes.c_double()
+    n = lib(libm).fsq_o_candidates(_p(img), H, W, int(med_size), _p(K), K.shape[0], ctypes.c_double(c_std),
+                                   _p(hw), cap, _p(cm), ctypes.byref(thr))
+    if n < 0:
+        raise ValueError("oracle candidates error %d" % n)
+    if return_cm:
+        return hw[:n].copy(), cm, thr.value
+    return hw[:n].copy()
+
+
+def fit_rois(rois, mode=0, n_threads=1, libm=False):
+    rois = np.ascontiguousarray(rois, dtype=np.uint16).reshape(-1, 25)
+    out = np.zeros(len(rois), FIT_DTYPE)
+    lib(libm).fsq_o_fit_rois_u16(_p(rois), len(rois), int(mode), int(n_threads), _p(out))
+    return out
+
+
+def model(p):
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    g = np.empty(25)
+    lib().fsq_o_model(_p(p), _p(g))
+    return g.reshape(5, 5)
+
+
+def illumina_s_n(roi, libm=False):
+    roi = np.ascontiguousarray(roi, dtype=np.int64)
+    return lib(libm).fsq_o_illumina_s_n(_p(roi))
+
+
+def find_peptides(img, med_size=5, K=DEFAULT_K, c_std=2.0, r2_thr=0.7, radius=4, mode=0, n_threads=1,
+                  libm=False):
+    """Returns (rows[all candidates], fits, keep_idx, key_hw)."""
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    K = np.ascontiguousarray(K, dtype=np.int64)
+    H, W = img.shape
+    cap = H * W
+    rows = np.zeros(cap, ROW_DTYPE)
+    fits = np.zeros(cap, FIT_DTYPE)
+    keep = np.zeros(cap, np.int32)
+    key = np.zeros((cap, 2), np.int32)
+    nc, nk = ctypes.c_int32(), ctypes.c_int32()
+    rc = lib(libm).fsq_o_find_peptides(_p(img), H, W, int(med_size), _p(K), K.shape[0],
+                                       ctypes.c_double(c_std), ctypes.c_double(r2_thr), int(radius),
+                                       int(mode), int(n_threads), _p(rows), _p(fits), _p(keep), _p(key),
+                                       cap, ctypes.byref(nc), ctypes.byref(nk))
+    if rc == -4:
+        raise AssertionError("pflib.py:518 assert")
+    if rc < 0:
+        raise ValueError("oracle find_peptides error %d" % rc)
+    return rows[:nc.value].copy(), fits[:nc.value].copy(), keep[:nk.value].copy(), key[:nk.value].copy()
+
+
+def enorm(x, inc=1):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    n = (len(x) + inc - 1) // inc
+    return lib().fsq_o_enorm(_p(x), n, inc)
