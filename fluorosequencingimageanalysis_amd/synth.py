@@ -51,6 +51,16 @@ def make_field(seed, shape=(512, 512), n_spots=200):
     return render(shape, r, c, a, seed)
 
 
+def make_hard_field(seed, shape=(256, 256), n_spots=150):
+    """Edge-case field: spots anywhere (also on the borders), overlapping, some saturating."""
+    rng = np.random.default_rng([seed, 0xBAD])
+    H, W = shape
+    r = rng.uniform(0.5, H - 0.5, n_spots)
+    c = rng.uniform(0.5, W - 0.5, n_spots)
+    a = 10 ** rng.uniform(2.5, 4.9, n_spots)
+    return render(shape, r, c, a, seed)
+
+
 def make_fields(seeds, shape=(512, 512), n_spots=500):
     """Stack of fields uint16[n, H, W] (cfg2: seeds 0..1023, 500 spots)."""
     return np.stack([make_field(s, shape, n_spots) for s in seeds])

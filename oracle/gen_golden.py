@@ -50,14 +50,7 @@ FIELDS = {
 def build_field(spec):
     if spec["kind"] == "std":
         return synth.make_field(spec["seed"], spec["shape"], spec["n_spots"])
-    # "hard": spots anywhere (also on the borders), overlapping, some saturating
-    rng = np.random.default_rng([spec["seed"], 0xBAD])
-    H, W = spec["shape"]
-    n = spec["n_spots"]
-    r = rng.uniform(0.5, H - 0.5, n)
-    c = rng.uniform(0.5, W - 0.5, n)
-    a = 10 ** rng.uniform(2.5, 4.9, n)
-    return synth.render(spec["shape"], r, c, a, spec["seed"])
+    return synth.make_hard_field(spec["seed"], spec["shape"], spec["n_spots"])
 
 
 _R = None

@@ -51,6 +51,8 @@ def lib(libm=False):
         L.fsq_o_enorm.restype = ctypes.c_double
         L.fsq_o_pairwise_sum.restype = ctypes.c_double
         L.fsq_o_pairwise_sum.argtypes = [ctypes.c_void_p, ctypes.c_long]
+        L.fsq_o_numpy_sum.restype = ctypes.c_double
+        L.fsq_o_numpy_sum.argtypes = [ctypes.c_void_p, ctypes.c_long]
         _libs[name] = L
     return _libs[name]
 
@@ -122,3 +124,15 @@ def enorm(x, inc=1):
     x = np.ascontiguousarray(x, dtype=np.float64)
     n = (len(x) + inc - 1) // inc
     return lib().fsq_o_enorm(_p(x), n, inc)
+
+
+def phase_correlate(ref, reg, upsample_factor=1):
+    ref = np.ascontiguousarray(ref, dtype=np.float64)
+    reg = np.ascontiguousarray(reg, dtype=np.float64)
+    if ref.shape != reg.shape or ref.ndim != 2:
+        raise ValueError("shape")
+    out = np.zeros(4)
+    rc = lib().fsq_o_phase_correlate(_p(ref), _p(reg), ref.shape[0], ref.shape[1], int(upsample_factor), _p(out))
+    if rc < 0:
+        raise ValueError("oracle phase_correlate error %d" % rc)
+    return tuple(out)
