@@ -1,0 +1,86 @@
+"""ctypes binding of libfsq_hip.so (C ABI declared in include/fsq.h).
+
+The HIP library IS the product: there is no CPU fallback.  Importing this module without the built
+library, or calling into it without a GPU, fails loudly."""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libfsq_hip.so")
+
+FSQ_OK, FSQ_EINVAL, FSQ_ENOMEM, FSQ_ERANGE, FSQ_EHIP, FSQ_EASSERT, FSQ_ENOTIMPL = 0, -1, -2, -3, -4, -5, -6
+MODE_REF, MODE_TEXTBOOK = 0, 1
+
+ROW_DTYPE = np.dtype([(k, np.float64) for k in
+                      ("h0", "w0", "H", "A", "sigma_h", "sigma_w", "theta", "rmse", "r2", "s_n", "p2", "p3")] +
+                     [(k, np.int32) for k in ("h", "w", "field", "status", "niter", "nfev", "key_h", "key_w")])
+assert ROW_DTYPE.itemsize == 128
+
+
+class FsqDetectParams(ctypes.Structure):
+    _fields_ = [("median_filter_size", ctypes.c_int32), ("ksz", ctypes.c_int32), ("c_std", ctypes.c_double),
+                ("K", ctypes.c_int64 * 81)]
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+_SIGS = {
+    "fsq_version": (ctypes.c_char_p, []),
+    "fsq_last_hip_error": (ctypes.c_char_p, []),
+    "fsq_device_count": (ctypes.c_int, []),
+    "fsq_detect_workspace_bytes": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "fsq_detect": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                  ctypes.POINTER(FsqDetectParams), ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "fsq_fit_candidates": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                          ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "fsq_fit_rois": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "fsq_consolidate_workspace_bytes": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "fsq_consolidate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "fsq_fit_images": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                      ctypes.c_void_p]),
+    "fsq_phase_correlate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+}
+EXPORTED = tuple(_SIGS)
+
+
+def lib():
+    """Load libfsq_hip.so (once). Raises NativeLibraryMissing if it was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryMissing(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C fluorosequencingimageanalysis_amd/csrc). There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            f = getattr(L, name)          # AttributeError if the library lacks a declared symbol
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc == FSQ_OK:
+        return
+    if rc == FSQ_EINVAL:
+        raise ValueError("%s: invalid argument" % what)
+    if rc == FSQ_EASSERT:
+        raise AssertionError("%s: re-keyed peak collides with an existing key (pflib.py:518)" % what)
+    if rc == FSQ_ENOTIMPL:
+        raise NotImplementedError(what)
+    if rc == FSQ_ENOMEM:
+        raise MemoryError(what)
+    if rc == FSQ_EHIP:
+        raise RuntimeError("%s: HIP error: %s" % (what, lib().fsq_last_hip_error().decode()))
+    raise RuntimeError("%s: error %d" % (what, rc))

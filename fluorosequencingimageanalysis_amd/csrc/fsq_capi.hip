@@ -1,0 +1,20 @@
+// fsq_capi.hip - library-level entry points of the C ABI (include/fsq.h)
+#include "fsq_common.h"
+
+thread_local hipError_t g_fsq_last_hip = hipSuccess;
+
+extern "C" const char* fsq_version(void) { return "fsq-hip 0.1 (gfx950)"; }
+extern "C" const char* fsq_last_hip_error(void) { return hipGetErrorString(g_fsq_last_hip); }
+extern "C" int fsq_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---- temporary stubs (replaced as the kernels land) ----
+extern "C" int64_t fsq_detect_workspace_bytes(int, int, int) { return 0; }
+extern "C" int fsq_detect(const uint16_t*, int, int, int, const FsqDetectParams*, int32_t*, int64_t, int32_t*, double*, void*, int64_t, void*) { return FSQ_ENOTIMPL; }
+extern "C" int64_t fsq_consolidate_workspace_bytes(int, int, int) { return 0; }
+extern "C" int fsq_consolidate(FsqRow*, const int32_t*, int, int, int, double, int, int, int32_t*, int32_t*, void*, int64_t, void*) { return FSQ_ENOTIMPL; }
+extern "C" int fsq_phase_correlate(const double*, const double*, int, int, int, int, double*, void*) { return FSQ_ENOTIMPL; }

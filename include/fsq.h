@@ -1,0 +1,110 @@
+/*
+ * fsq.h - C ABI of libfsq_hip.so: the MI355X (gfx950) implementation of the reference's per-field
+ * image hot path.  The reference (marcottelab/FluorosequencingImageAnalysis) is pure Python and has
+ * no FFI; these entry points are what a binding for that path binds instead of the Python bodies:
+ *
+ *   fsq_detect             <- pflib._psf_candidates            pflib.py:217-258
+ *   fsq_fit_candidates     <- the candidate loop of pflib.find_peptides (pflib.py:441-477):
+ *                             pflib._fit_2d_gaussian :180-214 -> gaussfitter.gaussfit
+ *                             (agpy/gaussfitter.py:142-255) -> mpfit (agpy/mpfit/mpfit.py:600-1388),
+ *                             then r_2 / rmse / illumina_s_n  (pflib.py:461-473, 261-281)
+ *   fsq_consolidate        <- R^2 filter + consolidation + re-key   pflib.py:466, 479-519
+ *   fsq_fit_images         <- gaussfitter.twodgaussian on the kept peaks  gaussfitter.py:253
+ *   fsq_phase_correlate    <- phase_correlate.phase_correlate  phase_correlate.py:11-134
+ *
+ * Conventions: every function returns 0 on success or a negative FSQ_E* code; nothing throws or
+ * aborts.  All pointers named d_* are DEVICE pointers (HBM); the caller owns every buffer.  `stream`
+ * is a hipStream_t passed as void*; functions only enqueue work on it and never synchronise unless
+ * stated.  Thread-safe for distinct streams/buffers.  INTEGRATION.md shows the Python-side binding.
+ */
+#ifndef FSQ_H
+#define FSQ_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSQ_OK         0
+#define FSQ_EINVAL   (-1)   /* bad argument: the reference raises ValueError (pflib.py:238, 432) */
+#define FSQ_ENOMEM   (-2)
+#define FSQ_ERANGE   (-3)   /* output capacity too small; *needed is set */
+#define FSQ_EHIP     (-4)   /* a HIP call failed (fsq_last_hip_error()) */
+#define FSQ_EASSERT  (-5)   /* the reference's assert at pflib.py:518 would fire */
+#define FSQ_ENOTIMPL (-6)   /* reference raises NotImplementedError (pflib.py:195) */
+
+#define FSQ_MODE_REF      0 /* reference-faithful fp64 LM (qrsolv/diag(R) aliasing of mpfit.py:1915) */
+#define FSQ_MODE_TEXTBOOK 1 /* same solver with MINPACK's diagonal restore */
+
+/* One fitted candidate: pflib's PSF tuple (pflib.py:475) without the two 5x5 images. 128 bytes. */
+typedef struct FsqRow {
+    double h0, w0, H, A, sigma_h, sigma_w, theta;   /* tuple[0..6]  (h0 = p2 + h - 2.5, pflib.py:461) */
+    double rmse, r2, s_n;                           /* tuple[9..11] */
+    double p2, p3;                                  /* fitter-frame centre, to rebuild fit_img exactly */
+    int32_t h, w, field;                            /* candidate pixel and field index */
+    int32_t status, niter, nfev;                    /* mpfit exit status, iterations, model evaluations */
+    int32_t key_h, key_w;                           /* dict key after consolidation (rounded centre) */
+} FsqRow;
+
+typedef struct FsqDetectParams {
+    int32_t median_filter_size;                     /* pflib default 5 */
+    int32_t ksz;                                    /* correlation_matrix side, odd */
+    double c_std;                                   /* pflib default 2 */
+    int64_t K[81];                                  /* correlation_matrix, row-major, ksz <= 9 */
+} FsqDetectParams;
+
+const char* fsq_version(void);
+const char* fsq_last_hip_error(void);
+int fsq_device_count(void);
+
+/* Workspace bytes fsq_detect needs for n_fields fields of H x W. */
+int64_t fsq_detect_workspace_bytes(int n_fields, int H, int W);
+
+/*
+ * Candidate detection for a batch of fields (raster order inside each field, fields in order).
+ *   d_img     uint16[n_fields][H][W]
+ *   d_cand    int32[cap][3]  (field, h, w)            out
+ *   d_counts  int32[n_fields + 1]                      out: per-field candidate counts, [n_fields] = total
+ *   d_thr     double[n_fields] (may be NULL)           out: mean + c_std * std of the response image
+ * If the total exceeds cap, d_counts is still complete and the call reports FSQ_ERANGE at the next
+ * fsq_detect_total().  Enqueue only.
+ */
+int fsq_detect(const uint16_t* d_img, int n_fields, int H, int W, const FsqDetectParams* prm,
+               int32_t* d_cand, int64_t cap, int32_t* d_counts, double* d_thr,
+               void* d_workspace, int64_t workspace_bytes, void* stream);
+
+/* LM-fit n candidates (any mix of fields); d_rows[n] out. Enqueue only. */
+int fsq_fit_candidates(const uint16_t* d_img, int n_fields, int H, int W, const int32_t* d_cand, int64_t n,
+                       int mode, FsqRow* d_rows, void* stream);
+
+/* Fit n stand-alone ROIs uint16[n][25] (pflib._fit_2d_gaussian surface); h = w = 2, field = 0. */
+int fsq_fit_rois(const uint16_t* d_rois, int64_t n, int mode, FsqRow* d_rows, void* stream);
+
+int64_t fsq_consolidate_workspace_bytes(int n_fields, int H, int W);
+/*
+ * R^2 filter + consolidation + re-key, per field, sequential reference semantics.
+ *   d_rows     FsqRow[n]: all fitted candidates, grouped by field in raster order (as fsq_detect emits)
+ *   d_counts   int32[n_fields+1] from fsq_detect
+ *   d_keep     int32[n]  out: indices into d_rows of kept peaks, per field in dict order
+ *   d_nkeep    int32[n_fields+1] out: kept per field, [n_fields] = total; -1 for a field whose
+ *              re-key assertion (pflib.py:518) fired
+ * key_h/key_w of the kept rows are filled in.
+ */
+int fsq_consolidate(FsqRow* d_rows, const int32_t* d_counts, int n_fields, int H, int W, double r2_threshold,
+                    int radius, int py2_round, int32_t* d_keep, int32_t* d_nkeep, void* d_workspace,
+                    int64_t workspace_bytes, void* stream);
+
+/* fit_img (double[n][25]) of rows selected by d_idx[n] (NULL = all first n rows). */
+int fsq_fit_images(const FsqRow* d_rows, const int32_t* d_idx, int64_t n, double* d_fit_img, void* stream);
+
+/*
+ * Registration of n_pairs image pairs (double[n_pairs][H][W] each), out4 = (row_shift, col_shift,
+ * error, diffphase) per pair, double[n_pairs][4].  Synchronises the stream (rocFFT plan + small
+ * host-side control).
+ */
+int fsq_phase_correlate(const double* d_ref, const double* d_reg, int n_pairs, int H, int W,
+                        int upsample_factor, double* d_out4, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
