@@ -12,9 +12,5 @@ extern "C" int fsq_device_count(void)
     return n;
 }
 
-// ---- temporary stubs (replaced as the kernels land) ----
-extern "C" int64_t fsq_detect_workspace_bytes(int, int, int) { return 0; }
-extern "C" int fsq_detect(const uint16_t*, int, int, int, const FsqDetectParams*, int32_t*, int64_t, int32_t*, double*, void*, int64_t, void*) { return FSQ_ENOTIMPL; }
-extern "C" int64_t fsq_consolidate_workspace_bytes(int, int, int) { return 0; }
-extern "C" int fsq_consolidate(FsqRow*, const int32_t*, int, int, int, double, int, int, int32_t*, int32_t*, void*, int64_t, void*) { return FSQ_ENOTIMPL; }
+// ---- temporary stub (replaced when fsq_register.hip lands) ----
 extern "C" int fsq_phase_correlate(const double*, const double*, int, int, int, int, double*, void*) { return FSQ_ENOTIMPL; }

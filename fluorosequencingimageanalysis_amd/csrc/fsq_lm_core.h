@@ -29,7 +29,9 @@ FSQ_DEV double np_clip(double x, double lo, double hi)
 }
 FSQ_DEV double fsq_sqrt(double x) { return __builtin_sqrt(x); }
 
-// numpy.dot(v, v) as OpenBLAS ddot evaluates it (see oracle/fsq_oracle.c dot_contig/dot_strided)
+// numpy.dot(v, v) as OpenBLAS 0.3.29 ddot (SkylakeX kernels) evaluates it: unit stride = 4x4 FMA lanes for the
+// first 16 elements folded ((a0+a1)+a2)+a3, (lo+hi), horizontal add, then a scalar FMA tail; non-unit stride = two
+// accumulators fed four products per step ("arithmetic model")
 FSQ_DEV double dot7(const double* x)
 {
     double d = 0.0;

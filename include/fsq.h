@@ -64,12 +64,14 @@ int64_t fsq_detect_workspace_bytes(int n_fields, int H, int W);
  *   d_img     uint16[n_fields][H][W]
  *   d_cand    int32[cap][3]  (field, h, w)            out
  *   d_counts  int32[n_fields + 1]                      out: per-field candidate counts, [n_fields] = total
+ *   d_offsets int32[n_fields + 1]                      out: exclusive prefix of d_counts (field f's
+ *                                                           candidates are d_cand[offsets[f] .. +counts[f]))
  *   d_thr     double[n_fields] (may be NULL)           out: mean + c_std * std of the response image
- * If the total exceeds cap, d_counts is still complete and the call reports FSQ_ERANGE at the next
- * fsq_detect_total().  Enqueue only.
+ * If the total exceeds cap only the first cap candidates are written; d_counts/d_offsets are still
+ * complete, so the caller can re-run with a larger buffer.  Enqueue only.
  */
 int fsq_detect(const uint16_t* d_img, int n_fields, int H, int W, const FsqDetectParams* prm,
-               int32_t* d_cand, int64_t cap, int32_t* d_counts, double* d_thr,
+               int32_t* d_cand, int64_t cap, int32_t* d_counts, int32_t* d_offsets, double* d_thr,
                void* d_workspace, int64_t workspace_bytes, void* stream);
 
 /* LM-fit n candidates (any mix of fields); d_rows[n] out. Enqueue only. */
@@ -83,13 +85,15 @@ int64_t fsq_consolidate_workspace_bytes(int n_fields, int H, int W);
 /*
  * R^2 filter + consolidation + re-key, per field, sequential reference semantics.
  *   d_rows     FsqRow[n]: all fitted candidates, grouped by field in raster order (as fsq_detect emits)
- *   d_counts   int32[n_fields+1] from fsq_detect
- *   d_keep     int32[n]  out: indices into d_rows of kept peaks, per field in dict order
+ *   d_counts, d_offsets   int32[n_fields+1] as fsq_detect emits them
+ *   d_keep     int32[n]  out: indices into d_rows of kept peaks; field f's kept indices are
+ *              d_keep[offsets[f] .. offsets[f] + nkeep[f]), in the reference's dict order
  *   d_nkeep    int32[n_fields+1] out: kept per field, [n_fields] = total; -1 for a field whose
  *              re-key assertion (pflib.py:518) fired
  * key_h/key_w of the kept rows are filled in.
  */
-int fsq_consolidate(FsqRow* d_rows, const int32_t* d_counts, int n_fields, int H, int W, double r2_threshold,
+int fsq_consolidate(FsqRow* d_rows, const int32_t* d_counts, const int32_t* d_offsets, int n_fields, int H, int W,
+                    double r2_threshold,
                     int radius, int py2_round, int32_t* d_keep, int32_t* d_nkeep, void* d_workspace,
                     int64_t workspace_bytes, void* stream);
 

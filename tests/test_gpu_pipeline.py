@@ -1,0 +1,121 @@
+"""GPU parity tests (-m gpu) of the whole per-field path through the drop-in surface
+(fluorosequencingimageanalysis_amd.pflib) and the C ABI, against the oracle and the reference's goldens."""
+import numpy as np
+import pytest
+
+from _util import FIELD_NAMES, bits_equal, load_field
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available()
+    import oracle as O
+    O.build()
+    from fluorosequencingimageanalysis_amd import pflib, engine
+    return torch, pflib, engine, O
+
+
+@pytest.mark.parametrize("name", FIELD_NAMES)
+def test_candidates_exact(env, name):
+    torch, pflib, engine, O = env
+    g, img = load_field(name)
+    got = pflib._psf_candidates(img)
+    assert got == [tuple(int(v) for v in hw) for hw in g["candidates"]]
+    assert all(isinstance(h, int) and isinstance(w, int) for h, w in got[:5])
+
+
+@pytest.mark.parametrize("name", FIELD_NAMES)
+def test_threshold_and_counts(env, name):
+    torch, pflib, engine, O = env
+    g, img = load_field(name)
+    H, W = img.shape
+    eng = engine.Engine(1, H, W)
+    total = eng.detect(engine.to_device_u16(img[None]), engine.detect_params(5, pflib.default_correlation_matrix, 2))
+    _, _, thr = O.candidates(img, return_cm=True)
+    assert eng.thr.cpu().numpy()[0] == thr             # numpy.mean + 2*numpy.std, bit for bit
+    assert total == len(g["candidates"])
+
+
+@pytest.mark.parametrize("name", FIELD_NAMES)
+def test_find_peptides_equals_reference(env, name):
+    """dict keys, order, the 12-tuples (incl. sub_img and fit_img) == the reference's own output."""
+    torch, pflib, engine, O = env
+    g, img = load_field(name)
+    d = pflib.find_peptides(img)
+    keys = np.array(list(d.keys()), dtype=np.int32).reshape(-1, 2)
+    assert np.array_equal(keys, g["table_keys"])
+    vals = list(d.values())
+    got7 = np.array([[float(x) for x in v[:7]] for v in vals]).reshape(-1, 7)
+    assert bits_equal(got7, g["table7"]).all()
+    gotm = np.array([[float(v[9]), float(v[10]), float(v[11])] for v in vals]).reshape(-1, 3)
+    assert bits_equal(gotm, g["table_metrics"]).all()
+    assert np.array_equal(np.array([v[7] for v in vals]).reshape(-1, 5, 5), g["table_sub"])
+    assert bits_equal(np.array([v[8] for v in vals]).reshape(-1, 5, 5), g["table_fit"]).all()
+    v = vals[0]
+    assert v[7].dtype == np.int64 and v[8].dtype == np.float64 and isinstance(v[9], float)
+
+
+def test_batch_equals_single(env):
+    torch, pflib, engine, O = env
+    imgs = np.stack([load_field("f0_cfg1_512_200")[1], load_field("f1_cfg2_512_500")[1]])
+    out = pflib.find_peptides_batch(imgs)
+    for f, name in enumerate(("f0_cfg1_512_200", "f1_cfg2_512_500")):
+        g, _ = load_field(name)
+        assert np.array_equal(np.array(list(out[f].keys()), dtype=np.int32).reshape(-1, 2), g["table_keys"])
+
+
+def test_nondefault_parameters(env):
+    """other median size / kernel / c_std / radius / threshold vs the oracle."""
+    torch, pflib, engine, O = env
+    g, img = load_field("f3_hard_256")
+    K = np.array([[-1, -2, -1], [-2, 13, -2], [-1, -2, -2]])
+    for med, KK, c_std, r2, rad in ((3, K, 1.5, 0.5, 2), (4, pflib.default_correlation_matrix, 2.5, 0.8, 6),
+                                    (7, np.array([[5]]), 3, 0.7, 3)):
+        cand = pflib._psf_candidates(img, median_filter_size=med, correlation_matrix=KK, c_std=c_std)
+        ref = O.candidates(img, med_size=med, K=KK, c_std=c_std)
+        assert cand == [tuple(int(v) for v in hw) for hw in ref]
+        d = pflib.find_peptides(img, median_filter_size=med, correlation_matrix=KK, c_std=c_std, r_2_threshold=r2,
+                                consolidation_radius=rad)
+        rows, fits, keep, key = O.find_peptides(img, med_size=med, K=KK, c_std=c_std, r2_thr=r2, radius=rad, n_threads=8)
+        assert np.array_equal(np.array(list(d.keys()), dtype=np.int32).reshape(-1, 2), key)
+        got = np.array([[float(x) for x in v[:7]] for v in d.values()]).reshape(-1, 7)
+        r = rows[keep]
+        exp = np.stack([r[k] for k in ("h0", "w0", "H", "A", "sigma_h", "sigma_w", "theta")], axis=1)
+        assert bits_equal(got, exp).all()
+
+
+def test_edge_cases(env):
+    torch, pflib, engine, O = env
+    # empty: a flat image has no candidates above threshold... (cm all zero -> thr 0 -> every interior pixel passes)
+    flat = np.full((16, 16), 100, np.uint16)
+    assert pflib._psf_candidates(flat) == [tuple(int(v) for v in hw) for hw in O.candidates(flat)]
+    tiny = np.full((5, 5), 7, np.uint16)
+    tiny[2, 2] = 900
+    assert pflib._psf_candidates(tiny) == [tuple(int(v) for v in hw) for hw in O.candidates(tiny)]
+    sat = np.full((32, 32), 65535, np.uint16)
+    assert pflib._psf_candidates(sat) == [tuple(int(v) for v in hw) for hw in O.candidates(sat)]
+    with pytest.raises(ValueError):
+        pflib.find_peptides(flat, consolidation_radius=1)
+    with pytest.raises(ValueError):
+        pflib._psf_candidates(flat, correlation_matrix=np.ones((4, 4), int))
+    with pytest.raises(NotImplementedError):
+        pflib._fit_2d_gaussian(np.zeros((5, 5), int), implementation='scipy')
+    with pytest.raises(AssertionError):
+        pflib._fit_2d_gaussian(np.zeros((4, 5), int))
+    with pytest.raises(NotImplementedError):
+        pflib.find_peptides(flat, fit_type='monte_carlo')
+
+
+def test_fit_2d_gaussian_surface(env):
+    torch, pflib, engine, O = env
+    g, img = load_field("f5_small_96")
+    h, w = g["candidates"][3]
+    sub = img[h - 2:h + 3, w - 2:w + 3].astype(np.int64)
+    r = pflib._fit_2d_gaussian(sub)
+    p = g["params"][3]
+    assert [float(x) for x in r[:7]] == [p[2], p[3], p[0], p[1], p[4], p[5], p[6]]
+    assert bits_equal(r[7], O.model(p)).all()
+    assert pflib.illumina_s_n(sub) == O.illumina_s_n(sub)

@@ -1,0 +1,91 @@
+"""CPU tests of the host-side logic and of the C ABI surface (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from _util import GOLD, ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    """libfsq_hip.so loads and exports each function include/fsq.h declares."""
+    from fluorosequencingimageanalysis_amd import _native
+    hdr = open(os.path.join(ROOT, "include", "fsq.h")).read()
+    declared = set(re.findall(r"\b(fsq_[a-z_0-9]+)\s*\(", hdr))
+    declared = {d for d in declared if not d.endswith("_total")}
+    assert declared == set(_native.EXPORTED), declared ^ set(_native.EXPORTED)
+    if not os.path.exists(_native.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    L = ctypes.CDLL(_native.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert _native.lib().fsq_version().startswith(b"fsq-hip")
+
+
+def test_row_struct_layout():
+    from fluorosequencingimageanalysis_amd import _native
+    assert _native.ROW_DTYPE.itemsize == 128
+    assert _native.ROW_DTYPE.fields["h"][1] == 96 and _native.ROW_DTYPE.fields["key_w"][1] == 124
+
+
+def test_epoch_hash_kat():
+    from fluorosequencingimageanalysis_amd import pflib
+    k = np.load(os.path.join(GOLD, "kat.npz"))
+    for e, h, back in zip(k["epochs"], k["epoch_hashes"], k["hash_epochs"]):
+        assert pflib._epoch_to_hash(float(e)) == str(h)
+        assert pflib._hash_to_epoch(str(h)) == int(back)
+    with pytest.raises(ValueError):
+        pflib._epoch_to_hash(0)
+    with pytest.raises(ValueError):
+        pflib._hash_to_epoch("ab!c")
+    assert pflib._psfs_filename("/x/y.tif", 36, ".pkl") == "/x/y.tif_psfs_10.pkl"
+
+
+def test_py2_str_and_csv(tmp_path):
+    from fluorosequencingimageanalysis_amd import pflib
+    assert pflib._py2_str(np.float64(2.0)) == "2.0"
+    assert pflib._py2_str(0.1 + 0.2) == "0.3"
+    assert pflib._py2_str(1234567.8901234567) == "1234567.89012"
+    assert pflib._py2_str(1e20) == "1e+20"
+    psfs = {(3, 4): (3.25, 4.5, 100.0, 2000.0, 1.1, 1.2, 0.0, np.zeros((5, 5), np.int64), np.zeros((5, 5)), 5.0, 0.9, 12.5)}
+    p = pflib.save_psfs_csv(psfs, output_path=str(tmp_path / "a.csv"), image_path="img.tif")
+    lines = open(p).read().splitlines()
+    assert lines[0].split("\t") == pflib.CSV_HEADER
+    assert lines[1].split("\t")[1:] == ["3.25", "4.5", "100.0", "2000.0", "1.1", "1.2", "0.0", "5.0", "0.9", "12.5"]
+    q = pflib.save_psfs_pkl(psfs, output_path=str(tmp_path / "a.pkl"))
+    import pickle
+    assert list(pickle.load(open(q, "rb")).keys()) == [(3, 4)]
+    with pytest.raises(ValueError):
+        pflib.save_psfs_csv(psfs)
+
+
+def test_parameter_validation_without_gpu():
+    from fluorosequencingimageanalysis_amd import engine, pflib
+    with pytest.raises(ValueError):
+        engine.detect_params(5, np.ones((4, 4)), 2)
+    with pytest.raises(ValueError):
+        engine.detect_params(5, np.ones((3, 5)), 2)
+    p = engine.detect_params(5, pflib.default_correlation_matrix, 2)
+    assert p.ksz == 5 and p.K[12] == 30742 and p.K[0] == -5935
+    with pytest.raises(ValueError):
+        pflib.find_peptides(np.zeros((16, 16), np.uint16), consolidation_radius=1)
+    with pytest.raises(NotImplementedError):
+        engine.as_u16_fields(np.zeros((4, 4), float))
+    with pytest.raises(NotImplementedError):
+        engine.as_u16_fields(np.array([[70000]]))
+    assert pflib.illumina_s_n(np.arange(25).reshape(5, 5)) == (24 - np.mean([0, 1, 2, 3, 4, 20, 21, 22, 23, 24, 5, 9, 10, 14, 15, 19])) / np.std([0, 1, 2, 3, 4, 20, 21, 22, 23, 24, 5, 9, 10, 14, 15, 19])
+    with pytest.raises(ValueError):
+        pflib.illumina_s_n(np.zeros((4, 5)))
+
+
+def test_product_does_not_import_oracle():
+    """the product path must not route through oracle/ (only tests/, smoke() and bench's cpu_baseline may)."""
+    pkg = os.path.join(ROOT, "fluorosequencingimageanalysis_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in src and "fsq_oracle" not in src and "libfsq_oracle" not in src, f
