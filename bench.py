@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the per-field hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[1]): 1 024 synthetic 512x512 uint16 fields per GPU, ~500 spots each
+(seeds rank*1024 .. +1023 of fluorosequencingimageanalysis_amd.synth), resident in HBM before the timed
+region.  One step = detect -> LM-fit every candidate -> R^2 filter + consolidation over the whole batch
+(+ the RCCL gather of the peak tables to rank 0 when N > 1).  value = candidate LM solves per second,
+whole job.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_FIT = 2.0e5            # reference-faithful LM solve, fp64 (plus ~4e3 exp, not counted)
+PEAK_FP64_VALU_TFLOPS = 78.6    # MI355X fp64 vector peak = 157.3 TFLOP/s fp32 vector / 2 (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def _make(seed_shape):
+    from fluorosequencingimageanalysis_amd import synth
+    seed, shape, n_spots = seed_shape
+    return synth.make_field(seed, shape, n_spots)
+
+
+def make_fields(seeds, shape, n_spots):
+    import multiprocessing as mp
+    n = min(16, os.cpu_count() or 1)
+    with mp.get_context("fork").Pool(n) as pool:
+        return np.stack(pool.map(_make, [(s, shape, n_spots) for s in seeds], chunksize=8))
+
+
+def cpu_baseline(imgs, cand, counts, offsets, n_threads):
+    """The oracle (C restatement of the reference) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    O.build()
+    n_fields = min(8, len(imgs))
+    n = int(offsets[n_fields])
+    c = cand[:n]
+    rois = np.stack([imgs[f, h - 2:h + 3, w - 2:w + 3] for f, h, w in c]).reshape(-1, 25)
+    O.fit_rois(rois[:256], n_threads=n_threads)        # warm-up
+    t = time.perf_counter()
+    O.fit_rois(rois, mode=0, n_threads=n_threads)
+    dt = time.perf_counter() - t
+    return {"value": n / dt, "unit": "fits/s", "cores": n_threads, "kind": "port",
+            "sample": "LM fits of all %d candidates of the first %d fields of the workload, oracle/fsq_oracle.c "
+                      "(reference-faithful fp64) on %d OpenMP threads, %.2f s" % (n, n_fields, n_threads, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--fields", type=int, default=1024, help="fields per GPU")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--spots", type=int, default=500)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from fluorosequencingimageanalysis_amd import _native as N
+    from fluorosequencingimageanalysis_amd import distributed as D
+    from fluorosequencingimageanalysis_amd import engine as E
+    from fluorosequencingimageanalysis_amd import pflib
+
+    rank, world, local = D.init_from_env()
+    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    assert torch.cuda.is_available(), "bench.py needs a GPU; the HIP path has no CPU fallback"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    shape = (a.size, a.size)
+    seeds = range(rank * a.fields, (rank + 1) * a.fields)
+    imgs = make_fields(seeds, shape, a.spots)
+    d_img = E.to_device_u16(imgs, dev)
+    eng = E.Engine(a.fields, a.size, a.size, device=dev)
+    prm = E.detect_params(5, pflib.default_correlation_matrix, 2)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * a.steps)]
+
+    def step(i=None):
+        total = eng.detect(d_img, prm)
+        if i is not None:
+            ev[2 * i].record()
+        eng.fit(d_img, total, N.MODE_REF)
+        if i is not None:
+            ev[2 * i + 1].record()
+        eng.consolidate(0.7, 4, True)
+        if world > 1:            # the one exchange of the path: peak tables to rank 0 over RCCL
+            nk = eng.nkeep.cpu().numpy()
+            offs = eng.offsets.cpu().numpy()
+            idx = np.concatenate([np.arange(offs[f], offs[f] + max(int(nk[f]), 0)) for f in range(a.fields)])
+            kept = eng.rows[:total].index_select(0, eng.keep[:total].index_select(0, torch.from_numpy(idx).to(dev)).long())
+            D.gather_tables(kept, 0)
+        return total
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    total = 0
+    for i in range(a.steps):
+        total = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt, float(total)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, total_all = float(tmax[0]), float(tsum[1])
+    else:
+        total_all = float(total)
+    fit_ms = [ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(a.steps)]
+    if rank == 0:
+        fit_avg_ms = float(np.mean(fit_ms))
+        fits_per_s = total_all * a.steps / dt
+        achieved = total * FLOP_PER_FIT / (fit_avg_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("fit_kernel_hbm_bytes_per_launch")
+        out = {
+            "metric": "psf_lm_fits_per_sec", "value": fits_per_s, "unit": "fits/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1]: %d synthetic %dx%d uint16 fields per GPU, %d spots each, "
+                                   "detect + LM-fit every candidate + consolidate (reference-faithful fp64)"
+                                   % (a.fields, a.size, a.size, a.spots),
+                       "fields_per_gpu": a.fields, "candidates_per_gpu": int(total),
+                       "parallelism": "fields sharded over %d rank(s), RCCL p2p gather of peak tables" % world},
+            "fields_per_sec": a.fields * world * a.steps / dt,
+            "roofline": {"bound": "valu-fp64 (no MFMA, ~1 GB/s of HBM: neither hbm nor mfma bounds this kernel)",
+                         "kernel": "fsq_fit_cand_kernel", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
+                         "launch_ms": fit_avg_ms, "fits_per_launch": int(total), "flop_per_fit": FLOP_PER_FIT},
+        }
+        if not a.no_cpu_baseline:
+            cand, counts, offsets = eng.candidates(total)
+            out["cpu_baseline"] = cpu_baseline(imgs, cand, counts, offsets, os.cpu_count() or 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

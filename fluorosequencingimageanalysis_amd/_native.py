@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libfsq_hip.so")
 
 FSQ_OK, FSQ_EINVAL, FSQ_ENOMEM, FSQ_ERANGE, FSQ_EHIP, FSQ_EASSERT, FSQ_ENOTIMPL = 0, -1, -2, -3, -4, -5, -6
-MODE_REF, MODE_TEXTBOOK = 0, 1
+MODE_REF, MODE_TEXTBOOK, ENGINE_LANE = 0, 1, 0x100
 
 ROW_DTYPE = np.dtype([(k, np.float64) for k in
                       ("h0", "w0", "H", "A", "sigma_h", "sigma_w", "theta", "rmse", "r2", "s_n", "p2", "p3")] +
@@ -38,9 +38,12 @@ _SIGS = {
     "fsq_detect": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                   ctypes.POINTER(FsqDetectParams), ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "fsq_fit_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64]),
     "fsq_fit_candidates": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
-                                          ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
-    "fsq_fit_rois": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+                                          ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                          ctypes.c_void_p]),
+    "fsq_fit_rois": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_int64, ctypes.c_void_p]),
     "fsq_consolidate_workspace_bytes": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "fsq_consolidate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,

@@ -1,5 +1,7 @@
 // fsq_fit.hip - K3/K4: per-candidate LM PSF fit + fit-quality metrics, one lane per candidate.
 // Reference: the candidate loop of pflib.find_peptides, pflib.py:441-477.
+#include <atomic>
+
 #include "fsq_common.h"
 #include "fsq_lm_core.h"
 
@@ -25,65 +27,88 @@ FSQ_DEV double fsq_illumina_s_n(const double* s, double vmax)
     return (vmax - mean) / sd;
 }
 
-template <bool ALIASED>
-FSQ_DEV void fsq_fit_one(const double* data, int h, int w, int field, FsqRow* row)
+// Work queue heads for the persistent fit kernels (one slot per in-flight launch, reset on the stream).
+__device__ unsigned long long g_fit_queue[256];
+
+FSQ_DEV void fsq_roi_stats(const double* data, double* vmedian, double* vmax, double* vmean)
 {
-    // start values of pflib._fit_2d_gaussian: median, max, mean of the ROI (pflib.py:201-209)
     double srt[FSQ_NPIX];
-    double vmax = data[0], isum = 0.0;
-    for (int i = 0; i < FSQ_NPIX; i++) { srt[i] = data[i]; vmax = data[i] > vmax ? data[i] : vmax; isum += data[i]; }
-    for (int i = 1; i < FSQ_NPIX; i++) {     // insertion sort (25 values)
+    double mx = data[0], isum = 0.0;
+    for (int i = 0; i < FSQ_NPIX; i++) { srt[i] = data[i]; mx = data[i] > mx ? data[i] : mx; isum += data[i]; }
+    for (int i = 1; i < FSQ_NPIX; i++) {
         double v = srt[i];
         int j = i - 1;
         while (j >= 0 && srt[j] > v) { srt[j + 1] = srt[j]; j--; }
         srt[j + 1] = v;
     }
-    double vmean = isum / 25.0;
-    FsqLmResult res;
-    fsq_lm_fit<ALIASED>(data, srt[12], vmax, vmean, &res);
-    // metrics, pflib.py:461-473
+    *vmedian = srt[12]; *vmax = mx; *vmean = isum / 25.0;
+}
+
+// fit-quality metrics and the output row (pflib.py:461-475)
+FSQ_DEV void fsq_finish_row(const double* data, const FsqLmState& st, int status, double vmax, double vmean,
+                            int h, int w, int field, FsqRow* row)
+{
     double fit[FSQ_NPIX];
-    fsq_model(res.p, fit);
+    fsq_model(st.x, fit);
     double num = 0.0, den = 0.0, rm = 0.0;
     for (int i = 0; i < FSQ_NPIX; i++) { double d = data[i] - fit[i]; num += d * d; }
     for (int i = 0; i < FSQ_NPIX; i++) { double d = data[i] - vmean; den += d * d; }
     for (int i = 0; i < FSQ_NPIX; i++) rm += fsq_pow2(data[i] - fit[i]);
-    row->h0 = res.p[2] + h - 2.5;
-    row->w0 = res.p[3] + w - 2.5;
-    row->H = res.p[0]; row->A = res.p[1]; row->sigma_h = res.p[4]; row->sigma_w = res.p[5]; row->theta = res.p[6];
+    row->h0 = st.x[2] + h - 2.5;
+    row->w0 = st.x[3] + w - 2.5;
+    row->H = st.x[0]; row->A = st.x[1]; row->sigma_h = st.x[4]; row->sigma_w = st.x[5]; row->theta = st.x[6];
     row->rmse = fsq_sqrt(rm / 25.0);
     row->r2 = 1.0 - num / den;
     row->s_n = fsq_illumina_s_n(data, vmax);
-    row->p2 = res.p[2]; row->p3 = res.p[3];
+    row->p2 = st.x[2]; row->p3 = st.x[3];
     row->h = h; row->w = w; row->field = field;
-    row->status = res.status; row->niter = res.niter; row->nfev = res.nfev;
+    row->status = status; row->niter = st.niter; row->nfev = st.nfev + (status > 0 ? 1 : 0);
     row->key_h = -1; row->key_w = -1;
 }
 
-template <bool ALIASED>
-__global__ void __launch_bounds__(64) fsq_fit_cand_kernel(const uint16_t* __restrict__ img, int H, int W,
-                                                          const int32_t* __restrict__ cand, int64_t n,
-                                                          FsqRow* __restrict__ rows)
+// Persistent kernel: every lane pulls candidates from a global queue; all lanes of a wave advance one
+// outer LM iteration per loop trip, and a lane whose fit has terminated refills immediately, so the
+// 1..200 iteration spread of the fits does not leave lanes idle.
+template <bool ALIASED, bool FROM_IMAGE>
+__global__ void __launch_bounds__(64) fsq_fit_persistent(const uint16_t* __restrict__ img, int H, int W,
+                                                         const int32_t* __restrict__ cand, long long n,
+                                                         FsqRow* __restrict__ rows, unsigned long long* __restrict__ queue)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int field = cand[3 * i], h = cand[3 * i + 1], w = cand[3 * i + 2];
-    const uint16_t* base = img + ((size_t)field * H + (h - 2)) * W + (w - 2);
+    FsqLmState st;
     double data[FSQ_NPIX];
-    for (int a = 0; a < 5; a++)
-        for (int b = 0; b < 5; b++) data[a * 5 + b] = (double)base[(size_t)a * W + b];
-    fsq_fit_one<ALIASED>(data, h, w, field, &rows[i]);
-}
-
-template <bool ALIASED>
-__global__ void __launch_bounds__(64) fsq_fit_roi_kernel(const uint16_t* __restrict__ rois, int64_t n,
-                                                         FsqRow* __restrict__ rows)
-{
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double data[FSQ_NPIX];
-    for (int k = 0; k < FSQ_NPIX; k++) data[k] = (double)rois[i * FSQ_NPIX + k];
-    fsq_fit_one<ALIASED>(data, 2, 2, 0, &rows[i]);
+    double vmax = 0., vmean = 0.;
+    long long idx = -1;
+    int h = 2, w = 2, field = 0;
+    bool active = false, drained = false;
+    for (;;) {
+        if (!active && !drained) {
+            idx = (long long)atomicAdd(queue, 1ull);
+            if (idx < n) {
+                if (FROM_IMAGE) {
+                    field = cand[3 * idx]; h = cand[3 * idx + 1]; w = cand[3 * idx + 2];
+                    const uint16_t* base = img + ((size_t)field * H + (h - 2)) * W + (w - 2);
+                    for (int a = 0; a < 5; a++)
+                        for (int b = 0; b < 5; b++) data[a * 5 + b] = (double)base[(size_t)a * W + b];
+                } else {
+                    for (int k = 0; k < FSQ_NPIX; k++) data[k] = (double)img[idx * FSQ_NPIX + k];
+                }
+                double vmedian;
+                fsq_roi_stats(data, &vmedian, &vmax, &vmean);
+                fsq_lm_init(data, vmedian, vmax, vmean, st);
+                active = true;
+            } else {
+                drained = true;
+            }
+        }
+        if (!__any(active)) break;
+        if (active) {
+            int status = fsq_lm_outer<ALIASED>(data, st);
+            if (status != 0) {
+                fsq_finish_row(data, st, status, vmax, vmean, h, w, field, &rows[idx]);
+                active = false;
+            }
+        }
+    }
 }
 
 __global__ void fsq_fit_images_kernel(const FsqRow* __restrict__ rows, const int32_t* __restrict__ idx, int64_t n,
@@ -98,31 +123,55 @@ __global__ void fsq_fit_images_kernel(const FsqRow* __restrict__ rows, const int
     for (int k = 0; k < FSQ_NPIX; k++) out[i * FSQ_NPIX + k] = g[k];
 }
 
-extern "C" int fsq_fit_candidates(const uint16_t* d_img, int n_fields, int H, int W, const int32_t* d_cand, int64_t n,
-                                  int mode, FsqRow* d_rows, void* stream)
+static int fsq_launch_fit(const uint16_t* d_src, int H, int W, const int32_t* d_cand, int64_t n, int mode, bool from_image,
+                          FsqRow* d_rows, hipStream_t s)
 {
-    if (n < 0 || H < 5 || W < 5 || n_fields < 1 || (mode != FSQ_MODE_REF && mode != FSQ_MODE_TEXTBOOK)) return FSQ_EINVAL;
-    if (n == 0) return FSQ_OK;
-    if (!d_img || !d_cand || !d_rows) return FSQ_EINVAL;
-    dim3 grid((unsigned)((n + 63) / 64)), block(64);
-    hipStream_t s = (hipStream_t)stream;
-    if (mode == FSQ_MODE_REF) hipLaunchKernelGGL(fsq_fit_cand_kernel<true>, grid, block, 0, s, d_img, H, W, d_cand, n, d_rows);
-    else hipLaunchKernelGGL(fsq_fit_cand_kernel<false>, grid, block, 0, s, d_img, H, W, d_cand, n, d_rows);
+    static std::atomic<unsigned> next_slot{0};
+    unsigned slot = next_slot.fetch_add(1) % 256u;
+    unsigned long long* queue = nullptr;
+    FSQ_HIP_CHECK(hipGetSymbolAddress((void**)&queue, HIP_SYMBOL(g_fit_queue)));
+    queue += slot;
+    FSQ_HIP_CHECK(hipMemsetAsync(queue, 0, sizeof(unsigned long long), s));
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    long long waves = (n + 63) / 64;
+    long long resident = (long long)cus * 8;               // persistent waves; more than fit at once is harmless
+    dim3 grid((unsigned)(waves < resident ? waves : resident)), block(64);
+    const bool ref = (mode == FSQ_MODE_REF);
+    if (from_image) {
+        if (ref) hipLaunchKernelGGL((fsq_fit_persistent<true, true>), grid, block, 0, s, d_src, H, W, d_cand, (long long)n, d_rows, queue);
+        else hipLaunchKernelGGL((fsq_fit_persistent<false, true>), grid, block, 0, s, d_src, H, W, d_cand, (long long)n, d_rows, queue);
+    } else {
+        if (ref) hipLaunchKernelGGL((fsq_fit_persistent<true, false>), grid, block, 0, s, d_src, 5, 5, d_cand, (long long)n, d_rows, queue);
+        else hipLaunchKernelGGL((fsq_fit_persistent<false, false>), grid, block, 0, s, d_src, 5, 5, d_cand, (long long)n, d_rows, queue);
+    }
     FSQ_HIP_CHECK(hipGetLastError());
     return FSQ_OK;
 }
 
-extern "C" int fsq_fit_rois(const uint16_t* d_rois, int64_t n, int mode, FsqRow* d_rows, void* stream)
+int fsq_launch_fit_quad(const uint16_t* d_src, int H, int W, const int32_t* d_cand, int64_t n, int mode, bool from_image,
+                        FsqRow* d_rows, void* d_ws, int64_t ws_bytes, hipStream_t s);
+
+extern "C" int fsq_fit_candidates(const uint16_t* d_img, int n_fields, int H, int W, const int32_t* d_cand, int64_t n,
+                                  int mode, FsqRow* d_rows, void* d_workspace, int64_t workspace_bytes, void* stream)
 {
-    if (n < 0 || (mode != FSQ_MODE_REF && mode != FSQ_MODE_TEXTBOOK)) return FSQ_EINVAL;
+    const int m = mode & 0xff;
+    if (n < 0 || H < 5 || W < 5 || n_fields < 1 || (m != FSQ_MODE_REF && m != FSQ_MODE_TEXTBOOK)) return FSQ_EINVAL;
+    if (n == 0) return FSQ_OK;
+    if (!d_img || !d_cand || !d_rows) return FSQ_EINVAL;
+    if (mode & FSQ_ENGINE_LANE) return fsq_launch_fit(d_img, H, W, d_cand, n, m, true, d_rows, (hipStream_t)stream);
+    return fsq_launch_fit_quad(d_img, H, W, d_cand, n, m, true, d_rows, d_workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int fsq_fit_rois(const uint16_t* d_rois, int64_t n, int mode, FsqRow* d_rows, void* d_workspace,
+                            int64_t workspace_bytes, void* stream)
+{
+    const int m = mode & 0xff;
+    if (n < 0 || (m != FSQ_MODE_REF && m != FSQ_MODE_TEXTBOOK)) return FSQ_EINVAL;
     if (n == 0) return FSQ_OK;
     if (!d_rois || !d_rows) return FSQ_EINVAL;
-    dim3 grid((unsigned)((n + 63) / 64)), block(64);
-    hipStream_t s = (hipStream_t)stream;
-    if (mode == FSQ_MODE_REF) hipLaunchKernelGGL(fsq_fit_roi_kernel<true>, grid, block, 0, s, d_rois, n, d_rows);
-    else hipLaunchKernelGGL(fsq_fit_roi_kernel<false>, grid, block, 0, s, d_rois, n, d_rows);
-    FSQ_HIP_CHECK(hipGetLastError());
-    return FSQ_OK;
+    if (mode & FSQ_ENGINE_LANE) return fsq_launch_fit(d_rois, 5, 5, nullptr, n, m, false, d_rows, (hipStream_t)stream);
+    return fsq_launch_fit_quad(d_rois, 5, 5, nullptr, n, m, false, d_rows, d_workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int fsq_fit_images(const FsqRow* d_rows, const int32_t* d_idx, int64_t n, double* d_fit_img, void* stream)

@@ -275,32 +275,56 @@ struct FsqLmResult {
     int status, niter, nfev;
 };
 
-// The fit.  data = the 5x5 ROI as doubles (exact integers).
+// Everything one fit carries from one outer LM iteration to the next (mpfit.py:1030 loop state).
+struct FsqLmState {
+    double x[FSQ_NP], diag[FSQ_NP], sdiag[FSQ_NP];
+    double fvec[FSQ_NPIX];
+    double llim1;                       // lower limit of the amplitude, (max - mean) / 3  (pflib.py:207-209)
+    double fnorm, fnorm1, par, delta, xnorm;
+    int niter, nfev;
+};
+
+FSQ_DEV double fsq_llim(int j, double llim1) { return j == 0 ? 0.00 : j == 1 ? llim1 : j < 4 ? 2.00 : j < 6 ? 0.75 : 0.00; }
+FSQ_DEV double fsq_ulim(int j) { return j < 2 ? 0.00 : j < 4 ? 3.00 : j < 6 ? 2.00 : 360.00; }
+FSQ_DEV bool fsq_qulim(int j) { return j >= 2; }
+
+// start of a fit: pflib._fit_2d_gaussian start values + gaussfit clipping + mpfit's first function call
+FSQ_DEV void fsq_lm_init(const double* data, double vmedian, double vmax, double vmean, FsqLmState& st)
+{
+    const int n = FSQ_NP;
+    double x0[FSQ_NP] = {vmedian, vmax, 2.5, 2.5, 1., 1., 0.};
+    st.llim1 = (vmax - vmean) / 3.0;
+    for (int i = 0; i < n; i++) {                       // gaussfitter.py:202-204
+        double v = x0[i];
+        if (v > fsq_ulim(i) && fsq_qulim(i)) v = fsq_ulim(i);
+        if (v < fsq_llim(i, st.llim1)) v = fsq_llim(i, st.llim1);
+        st.x[i] = v;
+        st.diag[i] = 0.; st.sdiag[i] = 0.;
+    }
+    fsq_residual(data, st.x, st.fvec);
+    st.nfev = 1; st.niter = 1;
+    st.fnorm = fsq_sqrt(dot25(st.fvec)); st.fnorm1 = -1.;
+    st.par = 0.; st.delta = 0.; st.xnorm = 0.;
+}
+
+// One pass of mpfit's outer loop (mpfit.py:1030-1340): Jacobian, QR, inner LM loop.  Returns the exit
+// status (0 = continue with another outer iteration).
 template <bool ALIASED>
-FSQ_DEV void fsq_lm_fit(const double* data, double vmedian, double vmax, double vmean, FsqLmResult* out)
+FSQ_DEV int fsq_lm_outer(const double* data, FsqLmState& st)
 {
     const int n = FSQ_NP, m = FSQ_NPIX;
-    double x[FSQ_NP] = {vmedian, vmax, 2.5, 2.5, 1., 1., 0.};
-    const bool qulim[FSQ_NP] = {false, false, true, true, true, true, true};     // all lower limits are on
-    const double llim[FSQ_NP] = {0.00, (vmax - vmean) / 3.0, 2.00, 2.00, 0.75, 0.75, 0.00};
-    const double ulim[FSQ_NP] = {0.00, 0.00, 3.00, 3.00, 2.00, 2.00, 360.00};
-    for (int i = 0; i < n; i++) {                       // gaussfitter.py:202-204
-        if (x[i] > ulim[i] && qulim[i]) x[i] = ulim[i];
-        if (x[i] < llim[i]) x[i] = llim[i];
-    }
-    double fvec[FSQ_NPIX], wa4[FSQ_NPIX], fjac[FSQ_NPIX * FSQ_NP];
-    double diag[FSQ_NP], qtf[FSQ_NP], wa1[FSQ_NP], wa2[FSQ_NP], wa3[FSQ_NP], acnorm[FSQ_NP], rdiag[FSQ_NP];
-    double xlm[FSQ_NP], sdiag[FSQ_NP], R[FSQ_NP * FSQ_NP];
+    double* x = st.x; double* fvec = st.fvec; double* diag = st.diag; double* sdiag = st.sdiag;
+    double llim[FSQ_NP], ulim[FSQ_NP]; bool qulim[FSQ_NP];
+    for (int j = 0; j < n; j++) { llim[j] = fsq_llim(j, st.llim1); ulim[j] = fsq_ulim(j); qulim[j] = fsq_qulim(j); }
+    double wa4[FSQ_NPIX], fjac[FSQ_NPIX * FSQ_NP];
+    double qtf[FSQ_NP], wa1[FSQ_NP], wa2[FSQ_NP], wa3[FSQ_NP], acnorm[FSQ_NP], rdiag[FSQ_NP];
+    double xlm[FSQ_NP], R[FSQ_NP * FSQ_NP];
     int ipvt[FSQ_NP];
-    int nfev = 0, niter = 1, status = 0;
-    fsq_residual(data, x, fvec); nfev++;
-    double fnorm = fsq_sqrt(dot25(fvec)), fnorm1 = -1.;
-    double par = 0., delta = 0., xnorm = 0., gnorm = 0.;
+    int nfev = st.nfev, niter = st.niter, status = 0;
+    double fnorm = st.fnorm, fnorm1 = st.fnorm1, par = st.par, delta = st.delta, xnorm = st.xnorm, gnorm = 0.;
     const double ftol = 1e-10, xtol = 1e-10, gtol = 1e-10, factor = 100.;
     const int maxiter = 200;
-    for (int j = 0; j < n; j++) { qtf[j] = 0.; sdiag[j] = 0.; }
-
-    for (;;) {
+    {
         // fdjac2, mpfit.py:1512-1612
         const double eps = 1.4901161193847656e-08;
         for (int j = 0; j < n; j++) {
@@ -365,7 +389,7 @@ FSQ_DEV void fsq_lm_fit(const double* data, double vmedian, double vmax, double 
                     gnorm = np_max2(gnorm, __builtin_fabs(s / acnorm[l]));
                 }
             }
-        if (gnorm <= gtol) { status = 4; break; }
+        if (gnorm <= gtol) { status = 4; goto done; }
         for (int j = 0; j < n; j++) diag[j] = (diag[j] > acnorm[j]) ? diag[j] : acnorm[j];
 
         for (;;) {                                       // inner loop, mpfit.py:1163
@@ -459,9 +483,21 @@ FSQ_DEV void fsq_lm_fit(const double* data, double vmedian, double vmax, double 
             for (int j = 0; j < n; j++) fin = fin && __builtin_isfinite(wa1[j]) && __builtin_isfinite(wa2[j]) && __builtin_isfinite(x[j]);
             if (!fin) { status = -16; break; }
         }
-        if (status != 0) break;
     }
-    if (status > 0) nfev++;        // mpfit's final function call (value unused by pflib)
-    for (int k = 0; k < n; k++) out->p[k] = x[k];
-    out->status = status; out->niter = niter; out->nfev = nfev;
+done:
+    st.nfev = nfev; st.niter = niter; st.fnorm = fnorm; st.fnorm1 = fnorm1; st.par = par; st.delta = delta; st.xnorm = xnorm;
+    return status;
+}
+
+// The fit, start to finish, for one lane (no work stealing): used for stand-alone ROIs.
+template <bool ALIASED>
+FSQ_DEV void fsq_lm_fit(const double* data, double vmedian, double vmax, double vmean, FsqLmResult* out)
+{
+    FsqLmState st;
+    fsq_lm_init(data, vmedian, vmax, vmean, st);
+    int status;
+    do { status = fsq_lm_outer<ALIASED>(data, st); } while (status == 0);
+    if (status > 0) st.nfev++;        // mpfit's final function call (value unused by pflib)
+    for (int k = 0; k < FSQ_NP; k++) out->p[k] = st.x[k];
+    out->status = status; out->niter = st.niter; out->nfev = st.nfev;
 }

@@ -1,0 +1,312 @@
+// fsq_lm_quad.h - the LM PSF fit mapped onto a QUAD of lanes (4 lanes per fit, 16 fits per wave).
+//
+// Same arithmetic, in the same order, as fsq_lm_core.h (and therefore as the reference's
+// mpfit/gaussfitter path); what changes is where the work and the data live on a CDNA4 CU:
+//   * the 25x7 Jacobian plus the residual vector are 8 columns; lane c of a quad owns columns c and
+//     c+4 in REGISTERS (2 x 25 doubles) - fdjac2's seven model evaluations, the column norms, the
+//     Householder updates and Q^T f all run column-parallel with no cross-lane sums, because every
+//     python sum() of the reference runs down a column;
+//   * the pivot column (the reflector) is broadcast inside the quad with ds_bpermute each step and
+//     the column registers shift up one row per step, so all register indices stay static;
+//   * the 7x7 part (R, lmpar, qrsolv, the trust-region bookkeeping) lives in LDS, one 8-byte slot per
+//     quad per element ([element][quad] layout: the 4 lanes of a quad broadcast-read the same address,
+//     different quads hit different banks) and is executed redundantly by the 4 lanes;
+//   * a wave advances all its 16 fits by one outer LM iteration per loop trip and refills finished
+//     quads from a global queue, so the 1..200 iteration spread costs no idle lanes.
+#pragma once
+#include "fsq_lm_core.h"
+
+// ---- LDS layout (units: doubles, per quad; element e of quad q lives at lds[(e)*16 + q]) ----------
+enum {
+    Q_X = 0, Q_DIAG = 7, Q_SDIAG = 14, Q_QTF = 21, Q_XLM = 28, Q_WA1 = 35, Q_WA2 = 42, Q_WA3 = 49,
+    Q_ACN = 56 /* acnorm by slot */, Q_RDIAG = 63 /* by logical position */, Q_WA = 70 /* by logical position */,
+    Q_R = 77 /* 7 rows x 7 slots: R(i,k) = Q_R + i*7 + slot(k) */, Q_FVEC = 126, Q_WA4 = 151, Q_DATA = 176,
+    Q_TMP = 201 /* 7 */, Q_TMP2 = 208 /* 7 */, Q_TMP3 = 215 /* 7 */, Q_END = 222
+};
+#define QL(off, e) lds[((off) + (e)) * 16 + quad]
+
+struct FsqQuadPrep {       // per candidate, written by the prep kernel
+    double vmedian, vmax, vmean;
+};
+
+// packed 4-bit lists (position -> slot and slot -> position)
+FSQ_DEV int nib_get(unsigned w, int k) { return (int)((w >> (4 * k)) & 15u); }
+FSQ_DEV unsigned nib_set(unsigned w, int k, int v) { return (w & ~(15u << (4 * k))) | ((unsigned)v << (4 * k)); }
+
+FSQ_DEV double quad_bcast(double v, int src_lane) { return __shfl(v, src_lane); }
+
+// OpenBLAS strided ddot pattern on a register column of `len` valid rows (positions 0..len-1)
+FSQ_DEV double dot_regcol(const double* x, int len)
+{
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int s = 0; s < 7; s++) {
+        if (4 * s + 3 < len) {
+            t2 += fsq_fma(x[4 * s + 1], x[4 * s + 1], x[4 * s + 3] * x[4 * s + 3]);
+            t1 += fsq_fma(x[4 * s], x[4 * s], x[4 * s + 2] * x[4 * s + 2]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (4 * s + r < 25 && 4 * s + r < len) t1 = fsq_fma(x[4 * s + r], x[4 * s + r], t1);
+        }
+    }
+    return t2 + t1;
+}
+// same pattern starting one row lower (enorm(a[j+1:, lk]) of the norm re-computation)
+FSQ_DEV double dot_regcol_from1(const double* x, int len)
+{
+    double t1 = 0.0, t2 = 0.0;
+    const int n = len - 1;
+#pragma unroll
+    for (int s = 0; s < 6; s++) {
+        if (4 * s + 3 < n) {
+            t2 += fsq_fma(x[4 * s + 2], x[4 * s + 2], x[4 * s + 4] * x[4 * s + 4]);
+            t1 += fsq_fma(x[4 * s + 1], x[4 * s + 1], x[4 * s + 3] * x[4 * s + 3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (4 * s + r + 1 < 25 && 4 * s + r < n) t1 = fsq_fma(x[4 * s + r + 1], x[4 * s + r + 1], t1);
+        }
+    }
+    return t2 + t1;
+}
+
+// model residuals data - g at parameters p, all 25 pixels into registers (data read from LDS)
+FSQ_DEV void quad_residual_regs(const double* lds, int quad, const double* p, double* r)
+{
+    double s, c;
+    fsq_sincos(FSQ_PI_180 * p[6], &s, &c);
+    const double rcen_x = p[3] * c - p[2] * s;
+    const double rcen_y = p[3] * s + p[2] * c;
+#pragma unroll
+    for (int xi = 0; xi < 5; xi++)
+#pragma unroll
+        for (int yi = 0; yi < 5; yi++) {
+            double x = (double)xi, y = (double)yi;
+            double xp = x * c - y * s;
+            double yp = x * s + y * c;
+            double u = (rcen_x - xp) / p[4];
+            double v = (rcen_y - yp) / p[5];
+            double e = -(u * u + v * v) / 2.;
+            double g = p[0] + p[1] * fsq_exp(e);
+            r[xi * 5 + yi] = QL(Q_DATA, xi * 5 + yi) - g;
+        }
+}
+
+// trial-point residuals: the 25 pixels are split over the 4 lanes of the quad, results go to LDS
+FSQ_DEV void quad_residual_split(double* lds, int quad, int c4, int p_off, int out_off)
+{
+    double p[FSQ_NP];
+#pragma unroll
+    for (int k = 0; k < FSQ_NP; k++) p[k] = QL(p_off, k);
+    double s, c;
+    fsq_sincos(FSQ_PI_180 * p[6], &s, &c);
+    const double rcen_x = p[3] * c - p[2] * s;
+    const double rcen_y = p[3] * s + p[2] * c;
+    for (int i = c4; i < FSQ_NPIX; i += 4) {
+        int xi = i / 5, yi = i - 5 * xi;
+        double x = (double)xi, y = (double)yi;
+        double xp = x * c - y * s;
+        double yp = x * s + y * c;
+        double u = (rcen_x - xp) / p[4];
+        double v = (rcen_y - yp) / p[5];
+        double e = -(u * u + v * v) / 2.;
+        double g = p[0] + p[1] * fsq_exp(e);
+        QL(out_off, i) = QL(Q_DATA, i) - g;
+    }
+}
+
+FSQ_DEV double lds_dot7(const double* lds, int quad, int off)
+{
+    double d = 0.0;
+#pragma unroll
+    for (int i = 0; i < 7; i++) { double v = QL(off, i); d = fsq_fma(v, v, d); }
+    return d;
+}
+FSQ_DEV double lds_dot25(const double* lds, int quad, int off)
+{
+    double S[4];
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        double a = QL(off, l), b = QL(off, 4 + l), c = QL(off, 8 + l), e = QL(off, 12 + l);
+        S[l] = ((a * a + b * b) + c * c) + e * e;
+    }
+    double d = (S[0] + S[2]) + (S[1] + S[3]);
+#pragma unroll
+    for (int i = 16; i < 25; i++) { double v = QL(off, i); d = fsq_fma(v, v, d); }
+    return d;
+}
+
+// R(i,k) with k a LOGICAL column: stored by slot
+#define QR(i, k) QL(Q_R, (i) * 7 + nib_get(ipvt, (k)))
+
+// mpfit.qrsolv on the LDS-resident R (mpfit.py:1903-1978); solution -> Q_XLM (by parameter index).
+// Loops are rolled on purpose (code size); wa lives in Q_TMP2, the saved diagonal (textbook mode) in Q_TMP3.
+template <bool ALIASED>
+FSQ_DEV void quad_qrsolv(double* lds, int quad, unsigned ipvt, int d_off /* sqrt(par)*diag, by parameter */)
+{
+    const int n = FSQ_NP;
+    for (int j = 0; j < n; j++)
+        for (int i = j; i < n; i++) QR(i, j) = QR(j, i);
+    for (int j = 0; j < n; j++) { if (!ALIASED) QL(Q_TMP3, j) = QR(j, j); QL(Q_TMP2, j) = QL(Q_QTF, j); }
+    for (int j = 0; j < n; j++) {
+        int l = nib_get(ipvt, j);
+        double dl = QL(d_off, l);
+        if (dl == 0) break;
+        for (int k = j; k < n; k++) QL(Q_SDIAG, k) = 0;
+        QL(Q_SDIAG, j) = dl;
+        double qtbpj = 0.;
+        for (int k = j; k < n; k++) {
+            double sk = QL(Q_SDIAG, k);
+            if (sk == 0) break;
+            double rkk = QR(k, k), sine, cosine;
+            if (__builtin_fabs(rkk) < __builtin_fabs(sk)) {
+                double cotan = rkk / sk;
+                sine = 0.5 / fsq_sqrt(.25 + .25 * cotan * cotan);
+                cosine = sine * cotan;
+            } else {
+                double tang = sk / rkk;
+                cosine = 0.5 / fsq_sqrt(.25 + .25 * tang * tang);
+                sine = cosine * tang;
+            }
+            QR(k, k) = cosine * rkk + sine * sk;
+            double wk = QL(Q_TMP2, k);
+            double temp = cosine * wk + sine * qtbpj;
+            qtbpj = -sine * wk + cosine * qtbpj;
+            QL(Q_TMP2, k) = temp;
+            for (int i = k + 1; i < n; i++) {
+                double rik = QR(i, k), si = QL(Q_SDIAG, i);
+                double t = cosine * rik + sine * si;
+                QL(Q_SDIAG, i) = -sine * rik + cosine * si;
+                QR(i, k) = t;
+            }
+        }
+        QL(Q_SDIAG, j) = QR(j, j);
+        if (!ALIASED) QR(j, j) = QL(Q_TMP3, j);
+    }
+    int nsing = n;
+    for (int j = n - 1; j >= 0; j--)
+        if (QL(Q_SDIAG, j) == 0) nsing = j;
+    for (int j = nsing; j < n; j++) QL(Q_TMP2, j) = 0;
+    if (nsing >= 1) {
+        QL(Q_TMP2, nsing - 1) = QL(Q_TMP2, nsing - 1) / QL(Q_SDIAG, nsing - 1);
+        for (int j = nsing - 2; j >= 0; j--) {
+            double s = 0.0;
+            for (int i = j + 1; i < nsing; i++) s += QR(i, j) * QL(Q_TMP2, i);
+            QL(Q_TMP2, j) = (QL(Q_TMP2, j) - s) / QL(Q_SDIAG, j);
+        }
+    }
+    for (int j = 0; j < n; j++) QL(Q_XLM, nib_get(ipvt, j)) = QL(Q_TMP2, j);
+    if (ALIASED)        // x aliases numpy.diagonal(r): r[m][m] = x[m] (mpfit.py:1915,1976-1977)
+        for (int j = 0; j < n; j++) QR(j, j) = QL(Q_XLM, j);
+}
+
+// mpfit.lmpar (mpfit.py:2077-2190) on the LDS state; returns par; step left in Q_XLM
+template <bool ALIASED>
+FSQ_DEV double quad_lmpar(double* lds, int quad, unsigned ipvt, double delta, double par)
+{
+    const int n = FSQ_NP;
+    double wa1[FSQ_NP], wa2[FSQ_NP];
+    int nsing = n;
+    double dmax = __builtin_fabs(QR(0, 0));
+#pragma unroll
+    for (int j = 1; j < n; j++) dmax = np_max2(dmax, __builtin_fabs(QR(j, j)));
+    const double rthresh = dmax * FSQ_MACHEP;
+#pragma unroll
+    for (int j = n - 1; j >= 0; j--)
+        if (__builtin_fabs(QR(j, j)) < rthresh) nsing = j;
+#pragma unroll
+    for (int j = 0; j < n; j++) wa1[j] = (j < nsing) ? QL(Q_QTF, j) : 0.0;
+#pragma unroll
+    for (int j = n - 1; j >= 0; j--)
+        if (j < nsing) {
+            wa1[j] = wa1[j] / QR(j, j);
+#pragma unroll
+            for (int i = 0; i < n; i++)
+                if (i < j) wa1[i] = wa1[i] - QR(i, j) * wa1[j];
+        }
+#pragma unroll
+    for (int j = 0; j < n; j++) QL(Q_XLM, nib_get(ipvt, j)) = wa1[j];
+#pragma unroll
+    for (int j = 0; j < n; j++) wa2[j] = QL(Q_DIAG, j) * QL(Q_XLM, j);
+    double dxnorm = 0.0;
+#pragma unroll
+    for (int j = 0; j < n; j++) dxnorm = fsq_fma(wa2[j], wa2[j], dxnorm);
+    dxnorm = fsq_sqrt(dxnorm);
+    double fp = dxnorm - delta;
+    if (fp <= 0.1 * delta) return 0.;
+    // wa2 is needed permuted: stash it in LDS
+#pragma unroll
+    for (int j = 0; j < n; j++) QL(Q_TMP, j) = wa2[j];
+    double parl = 0.;
+    if (nsing >= n) {
+#pragma unroll
+        for (int j = 0; j < n; j++) { int l = nib_get(ipvt, j); wa1[j] = QL(Q_DIAG, l) * QL(Q_TMP, l) / dxnorm; }
+        wa1[0] = wa1[0] / QR(0, 0);
+#pragma unroll
+        for (int j = 1; j < n; j++) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < n; i++)
+                if (i < j) s += QR(i, j) * wa1[i];
+            wa1[j] = (wa1[j] - s) / QR(j, j);
+        }
+        double temp = 0.0;
+#pragma unroll
+        for (int j = 0; j < n; j++) temp = fsq_fma(wa1[j], wa1[j], temp);
+        temp = fsq_sqrt(temp);
+        parl = ((fp / delta) / temp) / temp;
+    }
+#pragma unroll
+    for (int j = 0; j < n; j++) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < n; i++)
+            if (i <= j) s += QR(i, j) * QL(Q_QTF, i);
+        wa1[j] = s / QL(Q_DIAG, nib_get(ipvt, j));
+    }
+    double gnorm = 0.0;
+#pragma unroll
+    for (int j = 0; j < n; j++) gnorm = fsq_fma(wa1[j], wa1[j], gnorm);
+    gnorm = fsq_sqrt(gnorm);
+    double paru = gnorm / delta;
+    if (paru == 0) paru = FSQ_DWARF / np_min2(delta, 0.1);
+    par = np_max2(par, parl);
+    par = np_min2(par, paru);
+    if (par == 0) par = gnorm / dxnorm;
+    for (int iter = 1;; iter++) {
+        if (par == 0) par = np_max2(FSQ_DWARF, paru * 0.001);
+        double temp = fsq_sqrt(par);
+#pragma unroll
+        for (int j = 0; j < n; j++) QL(Q_WA1, j) = temp * QL(Q_DIAG, j);
+        quad_qrsolv<ALIASED>(lds, quad, ipvt, Q_WA1);
+#pragma unroll
+        for (int j = 0; j < n; j++) { wa2[j] = QL(Q_DIAG, j) * QL(Q_XLM, j); QL(Q_TMP, j) = wa2[j]; }
+        dxnorm = 0.0;
+#pragma unroll
+        for (int j = 0; j < n; j++) dxnorm = fsq_fma(wa2[j], wa2[j], dxnorm);
+        dxnorm = fsq_sqrt(dxnorm);
+        temp = fp;
+        fp = dxnorm - delta;
+        if ((__builtin_fabs(fp) <= 0.1 * delta) || ((parl == 0) && (fp <= temp) && (temp < 0)) || (iter == 10)) break;
+#pragma unroll
+        for (int j = 0; j < n; j++) { int l = nib_get(ipvt, j); wa1[j] = QL(Q_DIAG, l) * QL(Q_TMP, l) / dxnorm; }
+#pragma unroll
+        for (int j = 0; j < n - 1; j++) {
+            wa1[j] = wa1[j] / QL(Q_SDIAG, j);
+#pragma unroll
+            for (int i = 0; i < n; i++)
+                if (i > j) wa1[i] = wa1[i] - QR(i, j) * wa1[j];
+        }
+        wa1[n - 1] = wa1[n - 1] / QL(Q_SDIAG, n - 1);
+        temp = 0.0;
+#pragma unroll
+        for (int j = 0; j < n; j++) temp = fsq_fma(wa1[j], wa1[j], temp);
+        temp = fsq_sqrt(temp);
+        double parc = ((fp / delta) / temp) / temp;
+        if (fp > 0) parl = np_max2(parl, par);
+        if (fp < 0) paru = np_min2(paru, par);
+        par = np_max2(parl, par + parc);
+    }
+    return par;
+}

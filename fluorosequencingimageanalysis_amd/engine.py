@@ -89,6 +89,7 @@ class Engine:
         self.cand = torch.empty((self.cap, 3), dtype=torch.int32, device=self.dev)
         self.rows = torch.empty((self.cap, 128), dtype=torch.uint8, device=self.dev)
         self.keep = torch.empty(self.cap, dtype=torch.int32, device=self.dev)
+        self.fit_ws = torch.empty(self.L.fsq_fit_workspace_bytes(self.cap), dtype=torch.uint8, device=self.dev)
 
     def _stream(self):
         return self.torch.cuda.current_stream(self.dev).cuda_stream
@@ -107,7 +108,8 @@ class Engine:
 
     def fit(self, d_img, total, mode=N.MODE_REF):
         rc = self.L.fsq_fit_candidates(d_img.data_ptr(), self.n_fields, self.H, self.W, self.cand.data_ptr(), total,
-                                       mode, self.rows.data_ptr(), self._stream())
+                                       mode, self.rows.data_ptr(), self.fit_ws.data_ptr(), self.fit_ws.numel(),
+                                       self._stream())
         N.check(rc, "fsq_fit_candidates")
 
     def consolidate(self, r2_threshold, radius, py2_round=True):
@@ -171,6 +173,8 @@ def fit_rois(rois, mode=N.MODE_REF):
     r = as_u16_fields(rois).reshape(-1, 25)
     d = to_device_u16(r)
     rows = torch.empty((len(r), 128), dtype=torch.uint8, device=d.device)
-    rc = N.lib().fsq_fit_rois(d.data_ptr(), len(r), mode, rows.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    ws = torch.empty(N.lib().fsq_fit_workspace_bytes(len(r)), dtype=torch.uint8, device=d.device)
+    rc = N.lib().fsq_fit_rois(d.data_ptr(), len(r), mode, rows.data_ptr(), ws.data_ptr(), ws.numel(),
+                              torch.cuda.current_stream().cuda_stream)
     N.check(rc, "fsq_fit_rois")
     return rows.cpu().numpy().view(N.ROW_DTYPE).reshape(-1), rows

@@ -34,6 +34,7 @@ extern "C" {
 
 #define FSQ_MODE_REF      0 /* reference-faithful fp64 LM (qrsolv/diag(R) aliasing of mpfit.py:1915) */
 #define FSQ_MODE_TEXTBOOK 1 /* same solver with MINPACK's diagonal restore */
+#define FSQ_ENGINE_LANE 0x100 /* OR into mode: one GPU lane per fit instead of a quad of lanes */
 
 /* One fitted candidate: pflib's PSF tuple (pflib.py:475) without the two 5x5 images. 128 bytes. */
 typedef struct FsqRow {
@@ -74,12 +75,18 @@ int fsq_detect(const uint16_t* d_img, int n_fields, int H, int W, const FsqDetec
                int32_t* d_cand, int64_t cap, int32_t* d_counts, int32_t* d_offsets, double* d_thr,
                void* d_workspace, int64_t workspace_bytes, void* stream);
 
-/* LM-fit n candidates (any mix of fields); d_rows[n] out. Enqueue only. */
+/* Workspace bytes the fit entry points need for n candidates. */
+int64_t fsq_fit_workspace_bytes(int64_t n);
+
+/* LM-fit n candidates (any mix of fields); d_rows[n] out. Enqueue only.
+ * mode: FSQ_MODE_REF / FSQ_MODE_TEXTBOOK, optionally | FSQ_ENGINE_LANE to run the one-lane-per-fit
+ * engine instead of the default quad-cooperative one (same results; kept for A/B timing). */
 int fsq_fit_candidates(const uint16_t* d_img, int n_fields, int H, int W, const int32_t* d_cand, int64_t n,
-                       int mode, FsqRow* d_rows, void* stream);
+                       int mode, FsqRow* d_rows, void* d_workspace, int64_t workspace_bytes, void* stream);
 
 /* Fit n stand-alone ROIs uint16[n][25] (pflib._fit_2d_gaussian surface); h = w = 2, field = 0. */
-int fsq_fit_rois(const uint16_t* d_rois, int64_t n, int mode, FsqRow* d_rows, void* stream);
+int fsq_fit_rois(const uint16_t* d_rois, int64_t n, int mode, FsqRow* d_rows, void* d_workspace,
+                 int64_t workspace_bytes, void* stream);
 
 int64_t fsq_consolidate_workspace_bytes(int n_fields, int H, int W);
 /*

@@ -22,7 +22,9 @@ def env():
 def gpu_fit_rois(torch, N, rois, mode=0):
     d = torch.from_numpy(np.ascontiguousarray(rois.astype(np.uint16)).view(np.int16)).cuda()
     rows = torch.zeros(len(rois) * 128, dtype=torch.uint8, device="cuda")
-    rc = N.lib().fsq_fit_rois(d.data_ptr(), len(rois), mode, rows.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    ws = torch.zeros(N.lib().fsq_fit_workspace_bytes(len(rois)), dtype=torch.uint8, device="cuda")
+    rc = N.lib().fsq_fit_rois(d.data_ptr(), len(rois), mode, rows.data_ptr(), ws.data_ptr(), ws.numel(),
+                              torch.cuda.current_stream().cuda_stream)
     N.check(rc, "fsq_fit_rois")
     torch.cuda.synchronize()
     return rows.cpu().numpy().view(N.ROW_DTYPE)
@@ -44,6 +46,26 @@ def test_fit_rois_bit_exact_vs_oracle_and_golden(env, name):
     # and against the reference's own recorded outputs
     assert bits_equal(p, g["params"]).all()
     assert np.array_equal(got["status"], g["status"])
+    # metrics of every candidate vs the oracle (pflib.py:461-473)
+    exp = np.zeros(len(rois), O.ROW_DTYPE)
+    import ctypes
+    for i in range(0, len(rois), max(1, len(rois) // 200)):
+        roi = np.ascontiguousarray(rois[i].astype(np.int64))
+        O.lib().fsq_o_fit_metrics(roi.ctypes.data_as(ctypes.c_void_p), ref["p"][i].ctypes.data_as(ctypes.c_void_p), 2, 2,
+                                  exp[i:i + 1].ctypes.data_as(ctypes.c_void_p))
+        for k in ("h0", "w0", "rmse", "r2", "s_n"):
+            assert bits_equal(got[k][i], exp[k][i]).all(), (k, i)
+
+
+@pytest.mark.parametrize("name", ["f3_hard_256", "f1_cfg2_512_500"])
+def test_lane_engine_equals_quad_engine(env, name):
+    """the one-lane-per-fit engine (FSQ_ENGINE_LANE) and the quad engine give identical rows"""
+    torch, N, O = env
+    g, img = load_field(name)
+    rois = rois_of(img, g["candidates"])
+    a = gpu_fit_rois(torch, N, rois, mode=0)
+    b = gpu_fit_rois(torch, N, rois, mode=0 | N.ENGINE_LANE)
+    assert a.tobytes() == b.tobytes()
 
 
 def test_textbook_mode(env):

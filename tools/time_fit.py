@@ -7,10 +7,12 @@ reps=int(sys.argv[1]) if len(sys.argv)>1 else 64
 big=np.tile(rois,(reps,1)); n=len(big)
 d=torch.from_numpy(np.ascontiguousarray(big.astype(np.uint16)).view(np.int16)).cuda()
 rows=torch.zeros(n*128,dtype=torch.uint8,device='cuda')
+ws=torch.zeros(N.lib().fsq_fit_workspace_bytes(n),dtype=torch.uint8,device='cuda')
+mode=int(sys.argv[2]) if len(sys.argv)>2 else 0
 L=N.lib(); s=torch.cuda.current_stream().cuda_stream
 for it in range(3):
     torch.cuda.synchronize(); t=time.time()
-    N.check(L.fsq_fit_rois(d.data_ptr(),n,0,rows.data_ptr(),s),'fit'); torch.cuda.synchronize(); dt=time.time()-t
+    N.check(L.fsq_fit_rois(d.data_ptr(),n,mode,rows.data_ptr(),ws.data_ptr(),ws.numel(),s),'fit'); torch.cuda.synchronize(); dt=time.time()-t
     print('n=%d  %.3f s  %.3e fits/s'%(n,dt,n/dt))
 r=rows.cpu().numpy().view(N.ROW_DTYPE)
 print('mean nfev',r['nfev'].mean(),'niter',r['niter'].mean())
