@@ -10,6 +10,16 @@
 namespace {
 
 __device__ unsigned long long g_quad_queue[256];
+#ifdef FSQ_PHASE_PROFILE
+__device__ unsigned long long g_phase_cycles[16];
+#define PH_DECL unsigned long long ph_t0 = clock64(), ph_acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long ph_n_lmpar = 0, ph_n_trips = 0;
+#define PH_MARK(k) { unsigned long long t_ = clock64(); ph_acc[k] += t_ - ph_t0; ph_t0 = t_; }
+#define PH_FLUSH if (threadIdx.x == 0) { for (int k_ = 0; k_ < 8; k_++) atomicAdd(&g_phase_cycles[k_], ph_acc[k_]); atomicAdd(&g_phase_cycles[10], ph_acc[10]); atomicAdd(&g_phase_cycles[11], ph_acc[11]); atomicAdd(&g_phase_cycles[8], ph_n_lmpar); atomicAdd(&g_phase_cycles[9], ph_n_trips); }
+#else
+#define PH_DECL
+#define PH_MARK(k)
+#define PH_FLUSH
+#endif
 
 struct QuadOut {            // per candidate, written by k3_quad
     double p[FSQ_NP];
@@ -62,7 +72,7 @@ __global__ void __launch_bounds__(256) k3_prep(const uint16_t* __restrict__ src,
 
 // ---------------------------------------------------------------------------------------------------
 template <bool ALIASED, bool FROM_IMAGE>
-__global__ void __launch_bounds__(64, 2) k3_quad(const uint16_t* __restrict__ src, int H, int W,
+__global__ void __launch_bounds__(64, 1) k3_quad(const uint16_t* __restrict__ src, int H, int W,
                                                  const int32_t* __restrict__ cand, long long n,
                                                  const FsqQuadPrep* __restrict__ prep, QuadOut* __restrict__ out,
                                                  unsigned long long* __restrict__ queue)
@@ -76,7 +86,15 @@ __global__ void __launch_bounds__(64, 2) k3_quad(const uint16_t* __restrict__ sr
     double llim1 = 0., fnorm = 0., fnorm1 = -1., par = 0., delta = 0., xnorm = 0.;
     int niter = 1, nfev = 0;
     double ca[FSQ_NPIX], cb[FSQ_NPIX], refl[FSQ_NPIX];
-
+    // A quad is either waiting for a fresh Jacobian (need_jqr) or in the middle of mpfit's inner loop with
+    // R, qtf, diag held in registers (qlm).  One loop trip = [Jacobian + QR for the quads that need it] +
+    // [one lmpar/trial pass for every active quad]: a quad whose step is rejected simply takes another
+    // pass on the next trip while its neighbours move on to their next Jacobian.
+    bool need_jqr = true;
+    unsigned ipvt = 0x76543210u;        // position -> slot
+    double gnorm = 0.;
+    QuadLm qlm;
+    PH_DECL
     for (;;) {
         // ---- refill -------------------------------------------------------------------------------
         if (!active && !drained) {
@@ -101,17 +119,16 @@ __global__ void __launch_bounds__(64, 2) k3_quad(const uint16_t* __restrict__ sr
                     QL(Q_DIAG, i) = 0.; QL(Q_SDIAG, i) = 0.;
                 }
                 niter = 1; nfev = 0; fnorm1 = -1.; par = 0.; delta = 0.; xnorm = 0.;
-                active = true; fresh = true;
+                active = true; fresh = true; need_jqr = true;
             } else {
                 drained = true;
             }
         }
         if (!__any(active)) break;
-
+        PH_MARK(0)
         int status = 0;
-        unsigned ipvt = 0x76543210u;        // position -> slot
-        double gnorm = 0.;
-        if (active) {
+        if (active && need_jqr) {
+            ipvt = 0x76543210u;
             // ---- fdjac2 (mpfit.py:1512-1612): slot s = column s of the Jacobian, slot 7 = f(x) itself ---
             double xq[FSQ_NP];
 #pragma unroll
@@ -139,6 +156,7 @@ __global__ void __launch_bounds__(64, 2) k3_quad(const uint16_t* __restrict__ sr
                 if (pass == 0) { hA = hh; quad_residual_regs(lds, quad, xp, ca); }
                 else if (slot < 7 || fresh) { hB = hh; quad_residual_regs(lds, quad, xp, cb); }
             }
+            PH_MARK(1)
             if (fresh) {                    // mpfit's first function call (mpfit.py:999): fvec = f(x0)
                 if (c4 == 3) {
 #pragma unroll
@@ -183,6 +201,7 @@ __global__ void __launch_bounds__(64, 2) k3_quad(const uint16_t* __restrict__ sr
                     if (pegB) cb[i] = 0;
                 }
             }
+            PH_MARK(2)
             // ---- qrfac with column pivoting (mpfit.py:1748-1822), Q^T f fused in as slot 7 ----------
             {
                 double nA = fsq_sqrt(dot_regcol(ca, 25));
@@ -269,6 +288,7 @@ __global__ void __launch_bounds__(64, 2) k3_quad(const uint16_t* __restrict__ sr
 #pragma unroll
                 for (int i = 0; i + 1 < FSQ_NPIX; i++) { ca[i] = ca[i + 1]; cb[i] = cb[i + 1]; }
             }
+            PH_MARK(3)
             // ---- first iteration scaling, gradient test (mpfit.py:1099-1160) -----------------------
             if (niter == 1) {
 #pragma unroll
@@ -282,36 +302,46 @@ __global__ void __launch_bounds__(64, 2) k3_quad(const uint16_t* __restrict__ sr
                 delta = 100. * xnorm;
                 if (delta == 0.) delta = 100.;
             }
+            PH_MARK(4)
+            quadlm_load(qlm, lds, quad, ipvt);
+            PH_MARK(10)
             gnorm = 0.;
-            if (fnorm != 0)
-                for (int j = 0; j < n7; j++) {
-                    int l = nib_get(ipvt, j);
-                    double an = QL(Q_ACN, l);
+            if (fnorm != 0) {
+#pragma unroll
+                for (int j = 0; j < FSQ_NP; j++) {
+                    double an = QL(Q_ACN, nib_get(ipvt, j));
                     if (an != 0) {
-                        double s = 0.0;
-                        for (int i = 0; i <= j; i++) s += QR(i, j) * QL(Q_QTF, i);
-                        s = s / fnorm;
-                        gnorm = np_max2(gnorm, __builtin_fabs(s / an));
+                        double sg = 0.0;
+#pragma unroll
+                        for (int i = 0; i < FSQ_NP; i++)
+                            if (i <= j) sg += qlm.r[i][j] * qlm.qtf[i];
+                        sg = sg / fnorm;
+                        gnorm = np_max2(gnorm, __builtin_fabs(sg / an));
                     }
                 }
+            }
             if (gnorm <= 1e-10) status = 4;
             else {
 #pragma unroll
-                for (int k = 0; k < FSQ_NP; k++) { double dg = QL(Q_DIAG, k), an = QL(Q_ACN, k); QL(Q_DIAG, k) = (dg > an) ? dg : an; }
+                for (int k = 0; k < FSQ_NP; k++) { double dg = QL(Q_DIAG, k), an = QL(Q_ACN, k); dg = (dg > an) ? dg : an; QL(Q_DIAG, k) = dg; qlm.dg[k] = dg; }
+#pragma unroll
+                for (int j = 0; j < FSQ_NP; j++) qlm.dgp[j] = QL(Q_DIAG, nib_get(ipvt, j));
             }
+            need_jqr = false;
+            PH_MARK(11)
         }
-        // ---- inner loop (mpfit.py:1163-1335): lmpar, bounded step, trial point ----------------------
-        bool inner = active && (status == 0);
-        while (__any(inner)) {
-            if (inner) {
-                par = quad_lmpar<ALIASED>(lds, quad, ipvt, delta, par);
+        PH_MARK(4)
+        {
+            if (active && status == 0) {
+                par = quadlm_lmpar<ALIASED>(qlm, lds, quad, ipvt, delta, par);
+                PH_MARK(5)
                 double wa1[FSQ_NP], wa2[FSQ_NP], xq[FSQ_NP];
                 bool lpeg[FSQ_NP], upeg[FSQ_NP];
                 int nlpeg = 0, nupeg = 0;
 #pragma unroll
                 for (int k = 0; k < FSQ_NP; k++) {
                     xq[k] = QL(Q_X, k);
-                    wa1[k] = -QL(Q_XLM, k);
+                    wa1[k] = -qlm.xp[k];
                     lpeg[k] = (xq[k] == fsq_llim(k, llim1)); nlpeg += lpeg[k];
                     upeg[k] = fsq_qulim(k) && (xq[k] == fsq_ulim(k)); nupeg += upeg[k];
                 }
@@ -380,7 +410,7 @@ __global__ void __launch_bounds__(64, 2) k3_quad(const uint16_t* __restrict__ sr
                     double wj = QL(Q_WA1, nib_get(ipvt, j));
 #pragma unroll
                     for (int i = 0; i < FSQ_NP; i++)
-                        if (i <= j) wa3[i] = wa3[i] + QR(i, j) * wj;
+                        if (i <= j) wa3[i] = wa3[i] + qlm.r[i][j] * wj;
                 }
                 double t1s = 0.0;
 #pragma unroll
@@ -426,15 +456,19 @@ __global__ void __launch_bounds__(64, 2) k3_quad(const uint16_t* __restrict__ sr
                     if (delta <= FSQ_MACHEP * xnorm) status = 7;
                     if (gnorm <= FSQ_MACHEP) status = 8;
                 }
-                if (status != 0 || ratio >= 0.0001) inner = false;
-                else {
+                if (status == 0 && ratio >= 0.0001) need_jqr = true;       // accepted: next trip starts with a new Jacobian
+                if (status == 0 && ratio < 0.0001) {
                     bool fin = __builtin_isfinite(ratio);
 #pragma unroll
                     for (int k = 0; k < FSQ_NP; k++)
                         fin = fin && __builtin_isfinite(wa1[k]) && __builtin_isfinite(wa2[k]) && __builtin_isfinite(xq[k]);
-                    if (!fin) { status = -16; inner = false; }
+                    if (!fin) status = -16;
                 }
             }
+            PH_MARK(6)
+#ifdef FSQ_PHASE_PROFILE
+            ph_n_lmpar++;
+#endif
         }
         // ---- termination ------------------------------------------------------------------------------
         if (active && status != 0) {
@@ -447,7 +481,12 @@ __global__ void __launch_bounds__(64, 2) k3_quad(const uint16_t* __restrict__ sr
             }
             active = false;
         }
+        PH_MARK(7)
+#ifdef FSQ_PHASE_PROFILE
+        ph_n_trips++;
+#endif
     }
+    PH_FLUSH
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -499,6 +538,17 @@ __global__ void __launch_bounds__(64) k3_finish(const uint16_t* __restrict__ src
 }  // namespace
 
 // workspace: prep[n] + out[n]
+#ifdef FSQ_PHASE_PROFILE
+extern "C" int fsq_debug_phase_cycles(unsigned long long* out16, int reset)
+{
+    unsigned long long* p = nullptr;
+    if (hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_phase_cycles)) != hipSuccess) return -1;
+    if (hipMemcpy(out16, p, 16 * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (reset) (void)hipMemset(p, 0, 16 * 8);
+    return 0;
+}
+#endif
+
 extern "C" int64_t fsq_fit_workspace_bytes(int64_t n)
 {
     if (n < 0) return FSQ_EINVAL;

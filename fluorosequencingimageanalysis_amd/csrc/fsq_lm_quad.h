@@ -310,3 +310,222 @@ FSQ_DEV double quad_lmpar(double* lds, int quad, unsigned ipvt, double delta, do
     }
     return par;
 }
+
+
+// ---------------------------------------------------------------------------------------------------
+// Register-resident lmpar / qrsolv: R (logical column order) lives in 49 VGPR pairs, every index is
+// static after unrolling, so one qrsolv is ~28 rotations of pure VALU work with no LDS traffic.
+// Same operations in the same order as quad_lmpar / quad_qrsolv above.
+struct QuadLm {
+    double r[FSQ_NP][FSQ_NP];     // upper triangle = R, diagonal = (possibly aliased) diag, strict lower = S
+    double qtf[FSQ_NP];
+    double dg[FSQ_NP];            // diag by parameter index
+    double dgp[FSQ_NP];           // diag[ipvt[j]]
+    double sdiag[FSQ_NP];
+    double xp[FSQ_NP];            // solution by parameter index
+};
+
+FSQ_DEV void quadlm_load(QuadLm& q, const double* lds, int quad, unsigned ipvt)
+{
+#pragma unroll
+    for (int i = 0; i < FSQ_NP; i++)
+#pragma unroll
+        for (int k = 0; k < FSQ_NP; k++) q.r[i][k] = (k >= i) ? QR(i, k) : 0.0;
+#pragma unroll
+    for (int j = 0; j < FSQ_NP; j++) {
+        q.qtf[j] = QL(Q_QTF, j);
+        q.dg[j] = QL(Q_DIAG, j);
+        q.dgp[j] = QL(Q_DIAG, nib_get(ipvt, j));
+        q.sdiag[j] = QL(Q_SDIAG, j);
+    }
+}
+
+// scatter a logical-order vector to parameter order through LDS (x[ipvt[j]] = v[j])
+FSQ_DEV void quadlm_scatter(QuadLm& q, double* lds, int quad, unsigned ipvt, const double* v)
+{
+#pragma unroll
+    for (int j = 0; j < FSQ_NP; j++) QL(Q_XLM, nib_get(ipvt, j)) = v[j];
+#pragma unroll
+    for (int m = 0; m < FSQ_NP; m++) q.xp[m] = QL(Q_XLM, m);
+}
+
+template <bool ALIASED>
+FSQ_DEV void quadlm_qrsolv(QuadLm& q, double* lds, int quad, unsigned ipvt, double sqrt_par)
+{
+    const int n = FSQ_NP;
+    double wa[FSQ_NP], xsave[FSQ_NP];
+#pragma unroll
+    for (int j = 0; j < n; j++)
+#pragma unroll
+        for (int i = j + 1; i < n; i++) q.r[i][j] = q.r[j][i];
+#pragma unroll
+    for (int j = 0; j < n; j++) { xsave[j] = q.r[j][j]; wa[j] = q.qtf[j]; }
+    bool jstop = false;
+#pragma unroll
+    for (int j = 0; j < n; j++) {
+        const double dl = sqrt_par * q.dgp[j];          // (temp * diag)[ipvt[j]]
+        if (dl == 0) jstop = true;
+        if (!jstop) {
+#pragma unroll
+            for (int k = j; k < n; k++) q.sdiag[k] = 0;
+            q.sdiag[j] = dl;
+            double qtbpj = 0.;
+            bool kstop = false;
+#pragma unroll
+            for (int k = j; k < n; k++) {
+                const double sk = q.sdiag[k];
+                if (sk == 0) kstop = true;
+                if (!kstop) {
+                    const double rkk = q.r[k][k];
+                    const bool cnd = __builtin_fabs(rkk) < __builtin_fabs(sk);
+                    const double num = cnd ? rkk : sk, den = cnd ? sk : rkk;
+                    const double t = num / den;
+                    const double u = 0.5 / fsq_sqrt(.25 + .25 * t * t);
+                    const double v = u * t;
+                    const double cosine = cnd ? v : u, sine = cnd ? u : v;
+                    q.r[k][k] = cosine * rkk + sine * sk;
+                    const double temp = cosine * wa[k] + sine * qtbpj;
+                    qtbpj = -sine * wa[k] + cosine * qtbpj;
+                    wa[k] = temp;
+#pragma unroll
+                    for (int i = k + 1; i < n; i++) {
+                        const double rik = q.r[i][k], si = q.sdiag[i];
+                        const double tt = cosine * rik + sine * si;
+                        q.sdiag[i] = -sine * rik + cosine * si;
+                        q.r[i][k] = tt;
+                    }
+                }
+            }
+            q.sdiag[j] = q.r[j][j];
+            if (!ALIASED) q.r[j][j] = xsave[j];
+        }
+    }
+    int nsing = n;
+#pragma unroll
+    for (int j = n - 1; j >= 0; j--)
+        if (q.sdiag[j] == 0) nsing = j;
+#pragma unroll
+    for (int j = 0; j < n; j++)
+        if (j >= nsing) wa[j] = 0;
+#pragma unroll
+    for (int j = n - 1; j >= 0; j--) {
+        if (j == nsing - 1) wa[j] = wa[j] / q.sdiag[j];
+        else if (j < nsing - 1) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < n; i++)
+                if (i > j && i < nsing) s += q.r[i][j] * wa[i];
+            wa[j] = (wa[j] - s) / q.sdiag[j];
+        }
+    }
+    quadlm_scatter(q, lds, quad, ipvt, wa);
+    if (ALIASED) {
+#pragma unroll
+        for (int m = 0; m < n; m++) q.r[m][m] = q.xp[m];      // x IS numpy.diagonal(r)
+    }
+}
+
+// returns par; the step (by parameter index) is left in q.xp AND in LDS Q_XLM; R/sdiag are written back
+template <bool ALIASED>
+FSQ_DEV double quadlm_lmpar(QuadLm& q, double* lds, int quad, unsigned ipvt, double delta, double par)
+{
+    const int n = FSQ_NP;
+    double wa1[FSQ_NP], wa2[FSQ_NP];
+    int nsing = n;
+    double dmax = __builtin_fabs(q.r[0][0]);
+#pragma unroll
+    for (int j = 1; j < n; j++) dmax = np_max2(dmax, __builtin_fabs(q.r[j][j]));
+    const double rthresh = dmax * FSQ_MACHEP;
+#pragma unroll
+    for (int j = n - 1; j >= 0; j--)
+        if (__builtin_fabs(q.r[j][j]) < rthresh) nsing = j;
+#pragma unroll
+    for (int j = 0; j < n; j++) wa1[j] = (j < nsing) ? q.qtf[j] : 0.0;
+#pragma unroll
+    for (int j = n - 1; j >= 0; j--)
+        if (j < nsing) {
+            wa1[j] = wa1[j] / q.r[j][j];
+#pragma unroll
+            for (int i = 0; i < n; i++)
+                if (i < j) wa1[i] = wa1[i] - q.r[i][j] * wa1[j];
+        }
+    quadlm_scatter(q, lds, quad, ipvt, wa1);
+    double dxnorm = 0.0;
+#pragma unroll
+    for (int m = 0; m < n; m++) { double t = q.dg[m] * q.xp[m]; dxnorm = fsq_fma(t, t, dxnorm); }
+    dxnorm = fsq_sqrt(dxnorm);
+    double fp = dxnorm - delta;
+    if (fp <= 0.1 * delta) return 0.;
+    double parl = 0.;
+    if (nsing >= n) {
+#pragma unroll
+        for (int j = 0; j < n; j++) wa1[j] = q.dgp[j] * (q.dgp[j] * wa1[j]) / dxnorm;   // diag[l]*wa2[l]/dxnorm, wa2 = diag*x
+        wa1[0] = wa1[0] / q.r[0][0];
+#pragma unroll
+        for (int j = 1; j < n; j++) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < n; i++)
+                if (i < j) s += q.r[i][j] * wa1[i];
+            wa1[j] = (wa1[j] - s) / q.r[j][j];
+        }
+        double temp = 0.0;
+#pragma unroll
+        for (int j = 0; j < n; j++) temp = fsq_fma(wa1[j], wa1[j], temp);
+        temp = fsq_sqrt(temp);
+        parl = ((fp / delta) / temp) / temp;
+    }
+#pragma unroll
+    for (int j = 0; j < n; j++) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < n; i++)
+            if (i <= j) s += q.r[i][j] * q.qtf[i];
+        wa1[j] = s / q.dgp[j];
+    }
+    double gnorm = 0.0;
+#pragma unroll
+    for (int j = 0; j < n; j++) gnorm = fsq_fma(wa1[j], wa1[j], gnorm);
+    gnorm = fsq_sqrt(gnorm);
+    double paru = gnorm / delta;
+    if (paru == 0) paru = FSQ_DWARF / np_min2(delta, 0.1);
+    par = np_max2(par, parl);
+    par = np_min2(par, paru);
+    if (par == 0) par = gnorm / dxnorm;
+    for (int iter = 1;; iter++) {
+        if (par == 0) par = np_max2(FSQ_DWARF, paru * 0.001);
+        double temp = fsq_sqrt(par);
+        quadlm_qrsolv<ALIASED>(q, lds, quad, ipvt, temp);
+#pragma unroll
+        for (int m = 0; m < n; m++) wa2[m] = q.dg[m] * q.xp[m];
+        dxnorm = 0.0;
+#pragma unroll
+        for (int m = 0; m < n; m++) dxnorm = fsq_fma(wa2[m], wa2[m], dxnorm);
+        dxnorm = fsq_sqrt(dxnorm);
+        temp = fp;
+        fp = dxnorm - delta;
+        if ((__builtin_fabs(fp) <= 0.1 * delta) || ((parl == 0) && (fp <= temp) && (temp < 0)) || (iter == 10)) break;
+        // wa1 = diag[ipvt] * wa2[ipvt] / dxnorm : gather wa2 by logical position through LDS
+#pragma unroll
+        for (int m = 0; m < n; m++) QL(Q_TMP, m) = wa2[m];
+#pragma unroll
+        for (int j = 0; j < n; j++) wa1[j] = q.dgp[j] * QL(Q_TMP, nib_get(ipvt, j)) / dxnorm;
+#pragma unroll
+        for (int j = 0; j < n - 1; j++) {
+            wa1[j] = wa1[j] / q.sdiag[j];
+#pragma unroll
+            for (int i = 0; i < n; i++)
+                if (i > j) wa1[i] = wa1[i] - q.r[i][j] * wa1[j];
+        }
+        wa1[n - 1] = wa1[n - 1] / q.sdiag[n - 1];
+        temp = 0.0;
+#pragma unroll
+        for (int j = 0; j < n; j++) temp = fsq_fma(wa1[j], wa1[j], temp);
+        temp = fsq_sqrt(temp);
+        double parc = ((fp / delta) / temp) / temp;
+        if (fp > 0) parl = np_max2(parl, par);
+        if (fp < 0) paru = np_min2(paru, par);
+        par = np_max2(parl, par + parc);
+    }
+    return par;
+}
