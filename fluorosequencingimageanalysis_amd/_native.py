@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libfsq_hip.so")
 
 FSQ_OK, FSQ_EINVAL, FSQ_ENOMEM, FSQ_ERANGE, FSQ_EHIP, FSQ_EASSERT, FSQ_ENOTIMPL = 0, -1, -2, -3, -4, -5, -6
-MODE_REF, MODE_TEXTBOOK, ENGINE_LANE = 0, 1, 0x100
+MODE_REF, MODE_TEXTBOOK, ENGINE_LANE, ENGINE_QUAD = 0, 1, 0x100, 0x200
 
 ROW_DTYPE = np.dtype([(k, np.float64) for k in
                       ("h0", "w0", "H", "A", "sigma_h", "sigma_w", "theta", "rmse", "r2", "s_n", "p2", "p3")] +

@@ -151,6 +151,8 @@ static int fsq_launch_fit(const uint16_t* d_src, int H, int W, const int32_t* d_
 
 int fsq_launch_fit_quad(const uint16_t* d_src, int H, int W, const int32_t* d_cand, int64_t n, int mode, bool from_image,
                         FsqRow* d_rows, void* d_ws, int64_t ws_bytes, hipStream_t s);
+int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_cand, int64_t n, int mode, bool from_image,
+                          FsqRow* d_rows, void* d_ws, int64_t ws_bytes, hipStream_t s);
 
 extern "C" int fsq_fit_candidates(const uint16_t* d_img, int n_fields, int H, int W, const int32_t* d_cand, int64_t n,
                                   int mode, FsqRow* d_rows, void* d_workspace, int64_t workspace_bytes, void* stream)
@@ -160,7 +162,8 @@ extern "C" int fsq_fit_candidates(const uint16_t* d_img, int n_fields, int H, in
     if (n == 0) return FSQ_OK;
     if (!d_img || !d_cand || !d_rows) return FSQ_EINVAL;
     if (mode & FSQ_ENGINE_LANE) return fsq_launch_fit(d_img, H, W, d_cand, n, m, true, d_rows, (hipStream_t)stream);
-    return fsq_launch_fit_quad(d_img, H, W, d_cand, n, m, true, d_rows, d_workspace, workspace_bytes, (hipStream_t)stream);
+    if (mode & FSQ_ENGINE_QUAD) return fsq_launch_fit_quad(d_img, H, W, d_cand, n, m, true, d_rows, d_workspace, workspace_bytes, (hipStream_t)stream);
+    return fsq_launch_fit_rounds(d_img, H, W, d_cand, n, m, true, d_rows, d_workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int fsq_fit_rois(const uint16_t* d_rois, int64_t n, int mode, FsqRow* d_rows, void* d_workspace,
@@ -171,7 +174,8 @@ extern "C" int fsq_fit_rois(const uint16_t* d_rois, int64_t n, int mode, FsqRow*
     if (n == 0) return FSQ_OK;
     if (!d_rois || !d_rows) return FSQ_EINVAL;
     if (mode & FSQ_ENGINE_LANE) return fsq_launch_fit(d_rois, 5, 5, nullptr, n, m, false, d_rows, (hipStream_t)stream);
-    return fsq_launch_fit_quad(d_rois, 5, 5, nullptr, n, m, false, d_rows, d_workspace, workspace_bytes, (hipStream_t)stream);
+    if (mode & FSQ_ENGINE_QUAD) return fsq_launch_fit_quad(d_rois, 5, 5, nullptr, n, m, false, d_rows, d_workspace, workspace_bytes, (hipStream_t)stream);
+    return fsq_launch_fit_rounds(d_rois, 5, 5, nullptr, n, m, false, d_rows, d_workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int fsq_fit_images(const FsqRow* d_rows, const int32_t* d_idx, int64_t n, double* d_fit_img, void* stream)

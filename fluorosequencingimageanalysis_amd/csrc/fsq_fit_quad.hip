@@ -9,6 +9,10 @@
 
 namespace {
 
+// LDS hand-offs between the lanes of one wave: keep the compiler from moving LDS accesses across the point
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
 __device__ unsigned long long g_quad_queue[256];
 #ifdef FSQ_PHASE_PROFILE
 __device__ unsigned long long g_phase_cycles[16];
@@ -164,6 +168,7 @@ __global__ void __launch_bounds__(64, 1) k3_quad(const uint16_t* __restrict__ sr
                 }
                 nfev = 1;
             }
+            WAVE_SYNC();
             nfev += 7;
             if (fresh) { fnorm = fsq_sqrt(lds_dot25(lds, quad, Q_FVEC)); fresh = false; }
             // columns: (f(x + h e_j) - fvec) / h ; slot 7 gets a copy of fvec (it becomes Q^T f)
@@ -211,6 +216,7 @@ __global__ void __launch_bounds__(64, 1) k3_quad(const uint16_t* __restrict__ sr
                     QL(Q_ACN, c4 + 4) = nB; QL(Q_RDIAG, c4 + 4) = nB; QL(Q_WA, c4 + 4) = nB;
                 }
             }
+            WAVE_SYNC();
             unsigned pos = 0x76543210u;         // slot -> position
             bool broken = false;
             for (int j = 0; j < n7; j++) {
@@ -287,6 +293,7 @@ __global__ void __launch_bounds__(64, 1) k3_quad(const uint16_t* __restrict__ sr
                 // shift the columns up one row: row j+1 becomes position 0
 #pragma unroll
                 for (int i = 0; i + 1 < FSQ_NPIX; i++) { ca[i] = ca[i + 1]; cb[i] = cb[i + 1]; }
+                WAVE_SYNC();
             }
             PH_MARK(3)
             // ---- first iteration scaling, gradient test (mpfit.py:1099-1160) -----------------------
@@ -333,7 +340,7 @@ __global__ void __launch_bounds__(64, 1) k3_quad(const uint16_t* __restrict__ sr
         PH_MARK(4)
         {
             if (active && status == 0) {
-                par = quadlm_lmpar<ALIASED>(qlm, lds, quad, ipvt, delta, par);
+                par = quadlm_lmpar<ALIASED, 16>(qlm, &QL(Q_XLM, 0), ipvt, delta, par);
                 PH_MARK(5)
                 double wa1[FSQ_NP], wa2[FSQ_NP], xq[FSQ_NP];
                 bool lpeg[FSQ_NP], upeg[FSQ_NP];
@@ -549,16 +556,12 @@ extern "C" int fsq_debug_phase_cycles(unsigned long long* out16, int reset)
 }
 #endif
 
-extern "C" int64_t fsq_fit_workspace_bytes(int64_t n)
-{
-    if (n < 0) return FSQ_EINVAL;
-    return (int64_t)((n + 1) * (sizeof(FsqQuadPrep) + sizeof(QuadOut)) + 512);
-}
+static int64_t quad_ws_bytes(int64_t n) { return (int64_t)((n + 1) * (sizeof(FsqQuadPrep) + sizeof(QuadOut)) + 512); }
 
 int fsq_launch_fit_quad(const uint16_t* d_src, int H, int W, const int32_t* d_cand, int64_t n, int mode, bool from_image,
                         FsqRow* d_rows, void* d_ws, int64_t ws_bytes, hipStream_t s)
 {
-    if (ws_bytes < fsq_fit_workspace_bytes(n) || !d_ws) return FSQ_ENOMEM;
+    if (ws_bytes < quad_ws_bytes(n) || !d_ws) return FSQ_ENOMEM;
     FsqQuadPrep* prep = (FsqQuadPrep*)d_ws;
     QuadOut* qo = (QuadOut*)(((uintptr_t)(prep + n + 1) + 255) & ~(uintptr_t)255);
     static std::atomic<unsigned> next_slot{0};

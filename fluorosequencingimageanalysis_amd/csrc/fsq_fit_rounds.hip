@@ -1,0 +1,748 @@
+// fsq_fit_rounds.hip - K3/K4 production path: the LM fit as a WAVEFRONT of rounds over all candidates.
+//
+// Why: one LM solve is a chain of very different pieces - the Jacobian + pivoted QR (column-parallel,
+// regular) and mpfit's inner loop (lmpar with 0..10 qrsolv passes + a trial evaluation, scalar and wildly
+// irregular: a quarter of the lmpar calls run all 10 passes, most run 0-1, steps get rejected and retried).
+// Run in lockstep inside one wave the irregular part leaves 70% of the lanes idle (measured).  So every
+// candidate keeps its solver state in HBM (one ~0.8 KB record, AoS) and the fit advances in rounds:
+//   kA  "Jacobian round"  quad-cooperative (4 lanes per fit, columns in registers, see fsq_lm_quad.h):
+//                         fdjac2 + qrfac + Q^T f + gradient test            mpfit.py:1064-1160
+//   kB  "step round"      one lane per fit, R in registers: lmpar, bounded step, trial evaluation,
+//                         trust-region update, convergence tests             mpfit.py:1163-1335
+// Each kernel walks a list of candidate indices and appends every candidate to the list of the kernel it
+// needs next (accepted step -> kA, rejected step -> kB again, terminated -> done), so every wave of every
+// launch is full, whatever the iteration counts are.  Kernel boundaries give the inter-workgroup
+// visibility; no data-path collective, no atomics other than the list tails.
+// Arithmetic: identical, operation for operation, to fsq_lm_core.h (the reference's mpfit order).
+#include <atomic>
+#include <cstdlib>
+
+#include "fsq_common.h"
+#include "fsq_lm_quad.h"
+
+namespace {
+
+// LDS hand-offs between the lanes of one wave: keep the compiler from moving LDS accesses across the point
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+#ifdef FSQ_PHASE_PROFILE
+__device__ unsigned long long g_rphase[16];
+#define RPH_DECL unsigned long long rph_t0 = clock64(), rph_acc[8] = {0,0,0,0,0,0,0,0};
+#define RPH_MARK(k) { unsigned long long t_ = clock64(); rph_acc[k] += t_ - rph_t0; rph_t0 = t_; }
+#define RPH_FLUSH(off) if (threadIdx.x == 0) { for (int k_ = 0; k_ < 8; k_++) atomicAdd(&g_rphase[(off) + k_], rph_acc[k_]); }
+#else
+#define RPH_DECL
+#define RPH_MARK(k)
+#define RPH_FLUSH(off)
+#endif
+
+// ---- data layout in HBM ------------------------------------------------------------------------------
+// Work queues are structure-of-arrays indexed by QUEUE POSITION, so a wave reads its 64 (kB) or 16 (kA)
+// records with fully coalesced loads; a fit's live state travels with it from queue to queue:
+//   queue A record (input of kA):  idx | x[7] | diag[7] | llim1 fnorm par delta xnorm | niter,nfev      21 x 8 B
+//   queue B record (input of kB):  the same 21 + gnorm | ipvt | qtf[7] | sdiag[7] | R upper[28]          65 x 8 B
+// Indexed by candidate: fvec[25] (written on acceptance, read by kA), the final result, the ROI statistics.
+// The ROI pixels are re-read from the image (5 rows of 10 B) - they never change.
+enum { A_IDX = 0, A_X = 1, A_DIAG = 8, A_LLIM1 = 15, A_FNORM = 16, A_PAR = 17, A_DELTA = 18, A_XNORM = 19, A_ITER = 20,
+       A_LEN = 21,
+       B_GNORM = 21, B_IPVT = 22, B_QTF = 23, B_SDIAG = 30, B_R = 37, B_LEN = 65 };
+
+struct FitOut {               // by candidate: final parameters (written at termination)
+    double x[FSQ_NP];
+    int status, niter, nfev, pad;
+};
+struct FitStat {              // by candidate: ROI statistics (kinit)
+    double vmax, vmean;
+};
+
+struct Ctx {
+    const uint16_t* src; const int32_t* cand; int H, W; long long n; int from_image;
+    double* fvec;             // [n][25]
+    FitOut* out;              // [n]
+    FitStat* stat;            // [n]
+    long long cap;            // queue capacity (positions)
+};
+
+// Reserve one queue slot for every lane with `want` set: one atomic per wave (a single counter saturates at
+// ~90 atomics/us chip-wide, far below the millions of appends per round), slots in lane order.
+FSQ_DEV int wave_reserve(int* counter, bool want)
+{
+    const unsigned long long m = __ballot(want);
+    if (m == 0) return 0;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, leader);
+    return base + __popcll(m & ((1ull << lane) - 1ull));
+}
+
+FSQ_DEV int rpk(int i, int k) { return i * 7 - (i * (i - 1)) / 2 + (k - i); }     // index of (i,k), i <= k, in R upper[28]
+FSQ_DEV double pack2(int a, int b) { return __longlong_as_double(((long long)(unsigned)a) | ((long long)b << 32)); }
+FSQ_DEV void unpack2(double v, int* a, int* b) { long long u = __double_as_longlong(v); *a = (int)(unsigned)(u & 0xffffffffll); *b = (int)(u >> 32); }
+
+FSQ_DEV void roi_pixels(const Ctx& c, long long idx, double* d)
+{
+    if (c.from_image) {
+        const int f = c.cand[3 * idx], h = c.cand[3 * idx + 1], w = c.cand[3 * idx + 2];
+        const uint16_t* base = c.src + ((size_t)f * c.H + (h - 2)) * c.W + (w - 2);
+#pragma unroll
+        for (int a = 0; a < 5; a++)
+#pragma unroll
+            for (int b = 0; b < 5; b++) d[a * 5 + b] = (double)base[(size_t)a * c.W + b];
+    } else {
+#pragma unroll
+        for (int k = 0; k < FSQ_NPIX; k++) d[k] = (double)c.src[idx * FSQ_NPIX + k];
+    }
+}
+
+__global__ void __launch_bounds__(256) kinit(Ctx c, double* __restrict__ QA)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.n) return;
+    double v[FSQ_NPIX];
+    roi_pixels(c, i, v);
+    double mx = v[0], isum = 0.0;
+#pragma unroll
+    for (int k = 0; k < FSQ_NPIX; k++) { mx = v[k] > mx ? v[k] : mx; isum += v[k]; }
+#pragma unroll
+    for (int pass = 0; pass < FSQ_NPIX; pass++)          // odd-even transposition sort: median = v[12]
+#pragma unroll
+        for (int k = (pass & 1); k + 1 < FSQ_NPIX; k += 2) {
+            double a = v[k], b = v[k + 1];
+            v[k] = a < b ? a : b;
+            v[k + 1] = a < b ? b : a;
+        }
+    const double vmedian = v[12], vmean = isum / 25.0;
+    const double llim1 = (mx - vmean) / 3.0;                               // pflib.py:207-209
+    double x0[FSQ_NP] = {vmedian, mx, 2.5, 2.5, 1., 1., 0.};               // pflib.py:201-202
+    double* q = QA + i;
+    const long long cap = c.cap;
+#pragma unroll
+    for (int k = 0; k < FSQ_NP; k++) {                                     // gaussfitter.py:202-204
+        double t = x0[k];
+        if (t > fsq_ulim(k) && fsq_qulim(k)) t = fsq_ulim(k);
+        if (t < fsq_llim(k, llim1)) t = fsq_llim(k, llim1);
+        q[(A_X + k) * cap] = t;
+        q[(A_DIAG + k) * cap] = 0.;
+    }
+    q[A_IDX * cap] = pack2((int)i, 0);
+    q[A_LLIM1 * cap] = llim1; q[A_FNORM * cap] = 0.; q[A_PAR * cap] = 0.; q[A_DELTA * cap] = 0.; q[A_XNORM * cap] = 0.;
+    q[A_ITER * cap] = pack2(1, 0);                                         // niter = 1, nfev = 0  (nfev == 0 <=> fresh)
+    c.stat[i].vmax = mx; c.stat[i].vmean = vmean;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kA: Jacobian round.  block = 64 threads = 16 quads, grid-stride over list A.
+__global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __restrict__ QA, const int* __restrict__ cntA_p,
+                                                     double* __restrict__ QB, int* __restrict__ cntB_p)
+{
+    __shared__ double lds[Q_END * 16];
+    const int lane = threadIdx.x, quad = lane >> 2, c4 = lane & 3, qbase = lane & ~3;
+    const int n7 = FSQ_NP;
+    const int cntA = *cntA_p;
+    double ca[FSQ_NPIX], cb[FSQ_NPIX], refl[FSQ_NPIX];
+    for (int base = blockIdx.x * 16; base < cntA; base += gridDim.x * 16) {
+        const bool active = (base + quad) < cntA;
+        const long long cap = c.cap;
+        const double* qa = QA + (base + quad);
+        int idx = 0;
+        double llim1 = 0., fnorm = 0., xnorm = 0., delta = 0., par_in = 0.;
+        int niter = 1, nfev = 0;
+        bool fresh = false;
+        unsigned ipvt = 0x76543210u;
+        int status = 0;
+        double gnorm = 0.;
+        if (active) {
+            int dummy;
+            unpack2(qa[A_IDX * cap], &idx, &dummy);
+            unpack2(qa[A_ITER * cap], &niter, &nfev);
+            llim1 = qa[A_LLIM1 * cap]; fnorm = qa[A_FNORM * cap]; par_in = qa[A_PAR * cap]; delta = qa[A_DELTA * cap];
+            xnorm = qa[A_XNORM * cap];
+            fresh = (nfev == 0);
+            {
+                double d[FSQ_NPIX];
+                roi_pixels(c, idx, d);
+#pragma unroll
+                for (int k = 0; k < FSQ_NPIX; k++) QL(Q_DATA, k) = d[k];
+            }
+            if (!fresh) for (int k = c4; k < FSQ_NPIX; k += 4) QL(Q_FVEC, k) = c.fvec[(size_t)idx * FSQ_NPIX + k];
+            for (int k = c4; k < FSQ_NP; k += 4) { QL(Q_X, k) = qa[(A_X + k) * cap]; QL(Q_DIAG, k) = qa[(A_DIAG + k) * cap]; }
+        }
+        WAVE_SYNC();
+        if (active) {
+            // ---- fdjac2 (mpfit.py:1512-1612): slot s = column s of the Jacobian, slot 7 = f(x) itself ---
+            double xq[FSQ_NP];
+#pragma unroll
+            for (int k = 0; k < FSQ_NP; k++) xq[k] = QL(Q_X, k);
+            double hA = 0., hB = 0.;
+#pragma unroll
+            for (int pass = 0; pass < 2; pass++) {
+                const int slot = c4 + 4 * pass;
+                double xp[FSQ_NP];
+#pragma unroll
+                for (int k = 0; k < FSQ_NP; k++) xp[k] = xq[k];
+                double hh = 0.;
+                if (slot < 7) {
+                    double xs = xq[0];
+#pragma unroll
+                    for (int k = 1; k < FSQ_NP; k++) xs = (slot == k) ? xq[k] : xs;
+                    const double eps = 1.4901161193847656e-08;
+                    hh = eps * __builtin_fabs(xs);
+                    if (hh == 0) hh = eps;
+                    double ul = slot < 2 ? 0.0 : slot < 4 ? 3.0 : slot < 6 ? 2.0 : 360.0;
+                    if (slot >= 2 && (xs > ul - hh)) hh = -hh;
+#pragma unroll
+                    for (int k = 0; k < FSQ_NP; k++) xp[k] = (slot == k) ? (xq[k] + hh) : xq[k];
+                }
+                if (pass == 0) { hA = hh; quad_residual_regs(lds, quad, xp, ca); }
+                else if (slot < 7 || fresh) { hB = hh; quad_residual_regs(lds, quad, xp, cb); }
+            }
+            if (fresh) {                    // mpfit's first function call (mpfit.py:999): fvec = f(x0)
+                if (c4 == 3) {
+#pragma unroll
+                    for (int i = 0; i < FSQ_NPIX; i++) { QL(Q_FVEC, i) = cb[i]; c.fvec[(size_t)idx * FSQ_NPIX + i] = cb[i]; }
+                }
+                nfev = 1;
+            }
+            WAVE_SYNC();
+            nfev += 7;
+            if (fresh) fnorm = fsq_sqrt(lds_dot25(lds, quad, Q_FVEC));
+            bool pegA = false, pegB = false;
+            {
+                double sA = 0.0, sB = 0.0;
+#pragma unroll
+                for (int i = 0; i < FSQ_NPIX; i++) {
+                    double fv = QL(Q_FVEC, i);
+                    ca[i] = (ca[i] - fv) / hA;
+                    if (c4 < 3) cb[i] = (cb[i] - fv) / hB; else cb[i] = fv;
+                    sA += fv * ca[i];
+                    sB += fv * cb[i];
+                }
+                {   // pegged parameters (mpfit.py:1073-1091)
+                    const int slot = c4;
+                    double xs = xq[0];
+#pragma unroll
+                    for (int k = 1; k < FSQ_NP; k++) xs = (slot == k) ? xq[k] : xs;
+                    bool lp = (xs == fsq_llim(slot, llim1)), up = fsq_qulim(slot) && (xs == fsq_ulim(slot));
+                    pegA = (lp && sA > 0) || (up && sA < 0);
+                }
+                if (c4 < 3) {
+                    const int slot = c4 + 4;
+                    double xs = xq[4];
+#pragma unroll
+                    for (int k = 5; k < FSQ_NP; k++) xs = (slot == k) ? xq[k] : xs;
+                    bool lp = (xs == fsq_llim(slot, llim1)), up = (xs == fsq_ulim(slot));
+                    pegB = (lp && sB > 0) || (up && sB < 0);
+                }
+#pragma unroll
+                for (int i = 0; i < FSQ_NPIX; i++) {
+                    if (pegA) ca[i] = 0;
+                    if (pegB) cb[i] = 0;
+                }
+            }
+            // ---- qrfac with column pivoting (mpfit.py:1748-1822), Q^T f fused in as slot 7 ----------
+            {
+                double nA = fsq_sqrt(dot_regcol(ca, 25));
+                QL(Q_ACN, c4) = nA; QL(Q_RDIAG, c4) = nA; QL(Q_WA, c4) = nA;
+                if (c4 < 3) {
+                    double nB = fsq_sqrt(dot_regcol(cb, 25));
+                    QL(Q_ACN, c4 + 4) = nB; QL(Q_RDIAG, c4 + 4) = nB; QL(Q_WA, c4 + 4) = nB;
+                }
+            }
+            WAVE_SYNC();
+            unsigned pos = 0x76543210u;         // slot -> position
+            bool broken = false;
+            for (int j = 0; j < n7; j++) {
+                const int len = FSQ_NPIX - j;
+                if (!broken) {
+                    double rmax = QL(Q_RDIAG, j);
+                    for (int k = j + 1; k < n7; k++) rmax = np_max2(rmax, QL(Q_RDIAG, k));
+                    int kmax = -1;
+                    for (int k = n7 - 1; k >= j; k--)
+                        if (QL(Q_RDIAG, k) == rmax) kmax = k;
+                    if (kmax >= 0 && kmax != j) {
+                        int sj = nib_get(ipvt, j), sk = nib_get(ipvt, kmax);
+                        ipvt = nib_set(nib_set(ipvt, j, sk), kmax, sj);
+                        pos = nib_set(nib_set(pos, sk, j), sj, kmax);
+                        QL(Q_RDIAG, kmax) = QL(Q_RDIAG, j);
+                        QL(Q_WA, kmax) = QL(Q_WA, j);
+                    }
+                }
+                const int lj = nib_get(ipvt, j);
+                const int owner = qbase + (lj & 3);
+                const bool useB = (lj >> 2) != 0;
+#pragma unroll
+                for (int i = 0; i < FSQ_NPIX; i++) refl[i] = quad_bcast(useB ? cb[i] : ca[i], owner);
+                double ajj0;
+                if (!broken) {
+                    double ajnorm = fsq_sqrt(dot_regcol(refl, len));
+                    if (ajnorm == 0) broken = true;                 // mpfit.py:1790 `break`
+                    else {
+                        if (refl[0] < 0) ajnorm = -ajnorm;
+#pragma unroll
+                        for (int i = 0; i < FSQ_NPIX; i++)
+                            if (i < len) refl[i] = refl[i] / ajnorm;
+                        refl[0] = refl[0] + 1;
+                        QL(Q_TMP, 0) = -ajnorm;
+                    }
+                }
+                ajj0 = refl[0];
+#pragma unroll
+                for (int pass = 0; pass < 2; pass++) {
+                    const int slot = c4 + 4 * pass;
+                    double* col = pass ? cb : ca;
+                    const bool is_f = (slot == 7);
+                    const int k = is_f ? 7 : nib_get(pos, slot);
+                    const bool todo = is_f ? true : (!broken && k > j);
+                    if (todo && ajj0 != 0) {
+                        double s = 0.0;
+#pragma unroll
+                        for (int i = 0; i < FSQ_NPIX; i++)
+                            if (i < len) s += col[i] * refl[i];
+#pragma unroll
+                        for (int i = 0; i < FSQ_NPIX; i++)
+                            if (i < len) col[i] = col[i] - (refl[i] * s) / ajj0;
+                        if (!is_f) {
+                            double rk = QL(Q_RDIAG, k);
+                            if (rk != 0) {
+                                double temp = col[0] / rk;
+                                rk = rk * fsq_sqrt(np_max2(1. - fsq_pow2(temp), 0.));
+                                temp = rk / QL(Q_WA, k);
+                                if ((0.05 * temp * temp) <= FSQ_MACHEP) {
+                                    rk = fsq_sqrt(dot_regcol_from1(col, len));
+                                    QL(Q_WA, k) = rk;
+                                }
+                                QL(Q_RDIAG, k) = rk;
+                            }
+                        }
+                    }
+                    if (is_f) QL(Q_QTF, j) = col[0];
+                    else if (slot < 7 && nib_get(pos, slot) > j) QL(Q_R, j * 7 + slot) = col[0];
+                }
+                if (!broken) QL(Q_RDIAG, j) = QL(Q_TMP, 0);
+                QL(Q_R, j * 7 + lj) = QL(Q_RDIAG, j);               // fjac[j, lj] = rdiag[j] (mpfit.py:1123)
+#pragma unroll
+                for (int i = 0; i + 1 < FSQ_NPIX; i++) { ca[i] = ca[i + 1]; cb[i] = cb[i + 1]; }
+                WAVE_SYNC();
+            }
+            // ---- first iteration scaling, gradient test (mpfit.py:1099-1160) -----------------------
+            if (niter == 1) {
+#pragma unroll
+                for (int k = 0; k < FSQ_NP; k++) {
+                    double a = QL(Q_ACN, k);
+                    double dg = (a == 0) ? 1. : a;
+                    QL(Q_DIAG, k) = dg;
+                    QL(Q_WA3, k) = dg * QL(Q_X, k);
+                }
+                xnorm = fsq_sqrt(lds_dot7(lds, quad, Q_WA3));
+                delta = 100. * xnorm;
+                if (delta == 0.) delta = 100.;
+            }
+            gnorm = 0.;
+            if (fnorm != 0) {
+                for (int j = 0; j < n7; j++) {
+                    double an = QL(Q_ACN, nib_get(ipvt, j));
+                    if (an != 0) {
+                        double sg = 0.0;
+                        for (int i = 0; i <= j; i++) sg += QR(i, j) * QL(Q_QTF, i);
+                        sg = sg / fnorm;
+                        gnorm = np_max2(gnorm, __builtin_fabs(sg / an));
+                    }
+                }
+            }
+            if (gnorm <= 1e-10) status = 4;                                    // mpfit.py:1151
+            else {
+#pragma unroll
+                for (int k = 0; k < FSQ_NP; k++) { double dg = QL(Q_DIAG, k), an = QL(Q_ACN, k); QL(Q_DIAG, k) = (dg > an) ? dg : an; }
+            }
+            // ---- finish it (gradient test) ... ---------------------------------------------------------------
+            if (status != 0 && c4 == 0) {
+                FitOut o;
+#pragma unroll
+                for (int k = 0; k < FSQ_NP; k++) o.x[k] = QL(Q_X, k);
+                o.status = status; o.niter = niter; o.nfev = nfev; o.pad = 0;
+                c.out[idx] = o;
+            }
+        }
+        // ---- ... or hand it over to the step round: one queue-B slot per surviving quad -------------------------
+        {
+            const bool go = active && (status == 0);
+            int at = wave_reserve(cntB_p, go && c4 == 0);
+            at = __shfl(at, qbase);
+            if (go) {
+                double* qb = QB + at;
+                for (int e = c4; e < 28; e += 4) {
+                    int i = 0, rem = e;
+                    while (rem >= 7 - i) { rem -= 7 - i; i++; }
+                    qb[(B_R + e) * cap] = QR(i, i + rem);
+                }
+                for (int k = c4; k < FSQ_NP; k += 4) {
+                    qb[(A_X + k) * cap] = QL(Q_X, k);
+                    qb[(A_DIAG + k) * cap] = QL(Q_DIAG, k);
+                    qb[(B_QTF + k) * cap] = QL(Q_QTF, k);
+                    qb[(B_SDIAG + k) * cap] = 0.;
+                }
+                if (c4 == 0) {
+                    qb[A_IDX * cap] = pack2(idx, 0);
+                    qb[A_LLIM1 * cap] = llim1; qb[A_FNORM * cap] = fnorm; qb[A_PAR * cap] = par_in; qb[A_DELTA * cap] = delta;
+                    qb[A_XNORM * cap] = xnorm; qb[A_ITER * cap] = pack2(niter, nfev);
+                    qb[B_GNORM * cap] = gnorm; qb[B_IPVT * cap] = pack2((int)ipvt, 0);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kB: step round.  One lane per fit, grid-stride over list B.
+template <bool ALIASED>
+__global__ void __launch_bounds__(64, 1) kB_step(Ctx c, const double* __restrict__ QB, const int* __restrict__ cntB_p,
+                                                  double* __restrict__ QA_next, int* __restrict__ cntA_next,
+                                                  double* __restrict__ QB_next, int* __restrict__ cntB_next)
+{
+    __shared__ double scr[21 * 64];
+    const int lane = threadIdx.x;
+    const int cntB = *cntB_p;
+    double* myscr = scr + lane;
+    RPH_DECL
+    for (int base = blockIdx.x * 64; base < cntB; base += gridDim.x * 64) {
+        RPH_MARK(0)
+        const bool live = (base + lane) < cntB;
+        const int slot_in = live ? (base + lane) : 0;
+        const long long cap = c.cap;
+        const double* qb = QB + slot_in;
+        int idx, dummy, niter, nfev, ipvt_i;
+        unpack2(qb[A_IDX * cap], &idx, &dummy);
+        unpack2(qb[A_ITER * cap], &niter, &nfev);
+        unpack2(qb[B_IPVT * cap], &ipvt_i, &dummy);
+        const unsigned ipvt = (unsigned)ipvt_i;
+        QuadLm q;
+#pragma unroll
+        for (int i = 0; i < FSQ_NP; i++)
+#pragma unroll
+            for (int k = 0; k < FSQ_NP; k++) q.r[i][k] = (k >= i) ? qb[(B_R + rpk(i, k)) * cap] : 0.0;
+        double xq[FSQ_NP];
+#pragma unroll
+        for (int k = 0; k < FSQ_NP; k++) {
+            q.qtf[k] = qb[(B_QTF + k) * cap]; q.dg[k] = qb[(A_DIAG + k) * cap]; q.sdiag[k] = qb[(B_SDIAG + k) * cap];
+            xq[k] = qb[(A_X + k) * cap];
+        }
+        const double llim1 = qb[A_LLIM1 * cap], gnorm = qb[B_GNORM * cap];
+        double fnorm = qb[A_FNORM * cap], par = qb[A_PAR * cap], delta = qb[A_DELTA * cap], xnorm = qb[A_XNORM * cap], fnorm1;
+        double data[FSQ_NPIX];
+        roi_pixels(c, idx, data);
+#pragma unroll
+        for (int k = 0; k < FSQ_NP; k++) myscr[k * 64] = q.dg[k];
+#pragma unroll
+        for (int j = 0; j < FSQ_NP; j++) q.dgp[j] = myscr[nib_get(ipvt, j) * 64];
+
+        RPH_MARK(1)
+        par = quadlm_lmpar<ALIASED, 64>(q, myscr, ipvt, delta, par);
+        RPH_MARK(2)
+        double wa1[FSQ_NP], wa2[FSQ_NP];
+        bool lpeg[FSQ_NP], upeg[FSQ_NP];
+        int nlpeg = 0, nupeg = 0;
+#pragma unroll
+        for (int k = 0; k < FSQ_NP; k++) {
+            wa1[k] = -q.xp[k];
+            lpeg[k] = (xq[k] == fsq_llim(k, llim1)); nlpeg += lpeg[k];
+            upeg[k] = fsq_qulim(k) && (xq[k] == fsq_ulim(k)); nupeg += upeg[k];
+        }
+        double alpha = 1.;
+        if (nlpeg > 0) {
+            double mxw = wa1[0];
+#pragma unroll
+            for (int k = 1; k < FSQ_NP; k++) mxw = np_max2(mxw, wa1[k]);
+#pragma unroll
+            for (int k = 0; k < FSQ_NP; k++) if (lpeg[k]) wa1[k] = np_clip(wa1[k], 0., mxw);
+        }
+        if (nupeg > 0) {
+            double mnw = wa1[0];
+#pragma unroll
+            for (int k = 1; k < FSQ_NP; k++) mnw = np_min2(mnw, wa1[k]);
+#pragma unroll
+            for (int k = 0; k < FSQ_NP; k++) if (upeg[k]) wa1[k] = np_clip(wa1[k], mnw, 0.);
+        }
+        {
+            bool any = false; double tmin = 0.;
+#pragma unroll
+            for (int k = 0; k < FSQ_NP; k++)
+                if ((__builtin_fabs(wa1[k]) > FSQ_MACHEP) && ((xq[k] + wa1[k]) < fsq_llim(k, llim1))) {
+                    double t = (fsq_llim(k, llim1) - xq[k]) / wa1[k];
+                    tmin = any ? np_min2(tmin, t) : t; any = true;
+                }
+            if (any) alpha = np_min2(alpha, tmin);
+            any = false;
+#pragma unroll
+            for (int k = 0; k < FSQ_NP; k++)
+                if ((__builtin_fabs(wa1[k]) > FSQ_MACHEP) && fsq_qulim(k) && ((xq[k] + wa1[k]) > fsq_ulim(k))) {
+                    double t = (fsq_ulim(k) - xq[k]) / wa1[k];
+                    tmin = any ? np_min2(tmin, t) : t; any = true;
+                }
+            if (any) alpha = np_min2(alpha, tmin);
+        }
+        double pnorm = 0.0;
+#pragma unroll
+        for (int k = 0; k < FSQ_NP; k++) {
+            wa1[k] = wa1[k] * alpha;
+            wa2[k] = xq[k] + wa1[k];
+            const double ul = fsq_ulim(k), ll = fsq_llim(k, llim1);
+            double sgnu = (ul >= 0) * 2. - 1., sgnl = (ll >= 0) * 2. - 1.;
+            double ulim1 = ul * (1 - sgnu * FSQ_MACHEP) - (ul == 0) * FSQ_MACHEP;
+            double llim1_ = ll * (1 + sgnl * FSQ_MACHEP) + (ll == 0) * FSQ_MACHEP;
+            if (fsq_qulim(k) && (wa2[k] >= ulim1)) wa2[k] = ul;
+            if (wa2[k] <= llim1_) wa2[k] = ll;
+            double t = q.dg[k] * wa1[k];
+            pnorm = fsq_fma(t, t, pnorm);
+            myscr[(14 + k) * 64] = wa1[k];
+        }
+        pnorm = fsq_sqrt(pnorm);
+        if (niter == 1) delta = np_min2(delta, pnorm);
+        RPH_MARK(3)
+        // trial evaluation (mpfit.py:1245)
+        double wa4[FSQ_NPIX];
+        {
+            double g[FSQ_NPIX];
+            fsq_model(wa2, g);
+#pragma unroll
+            for (int i = 0; i < FSQ_NPIX; i++) wa4[i] = data[i] - g[i];
+        }
+        nfev++;
+        fnorm1 = fsq_sqrt(dot25(wa4));
+        RPH_MARK(4)
+        double actred = -1.;
+        if ((0.1 * fnorm1) < fnorm) actred = -fsq_pow2(fnorm1 / fnorm) + 1.;
+        double wa3[FSQ_NP];
+#pragma unroll
+        for (int k = 0; k < FSQ_NP; k++) wa3[k] = 0.;
+#pragma unroll
+        for (int j = 0; j < FSQ_NP; j++) {
+            wa3[j] = 0;
+            double wj = myscr[(14 + nib_get(ipvt, j)) * 64];
+#pragma unroll
+            for (int i = 0; i < FSQ_NP; i++)
+                if (i <= j) wa3[i] = wa3[i] + q.r[i][j] * wj;
+        }
+        double t1s = 0.0;
+#pragma unroll
+        for (int k = 0; k < FSQ_NP; k++) { double t = alpha * wa3[k]; t1s = fsq_fma(t, t, t1s); }
+        double temp1 = fsq_sqrt(t1s) / fnorm;
+        double temp2 = (fsq_sqrt(alpha * par) * pnorm) / fnorm;
+        double prered = temp1 * temp1 + (temp2 * temp2) / 0.5;
+        double dirder = -(temp1 * temp1 + temp2 * temp2);
+        double ratio = 0.;
+        if (prered != 0) ratio = actred / prered;
+        if (ratio <= 0.25) {
+            double temp;
+            if (actred >= 0) temp = .5;
+            else temp = .5 * dirder / (dirder + .5 * actred);
+            if (((0.1 * fnorm1) >= fnorm) || (temp < 0.1)) temp = 0.1;
+            delta = temp * np_min2(delta, pnorm / 0.1);
+            par = par / temp;
+        } else if ((par == 0) || (ratio >= 0.75)) {
+            delta = pnorm / .5;
+            par = .5 * par;
+        }
+        const bool accepted = (ratio >= 0.0001);
+        if (accepted) {
+            double xs = 0.0;
+#pragma unroll
+            for (int k = 0; k < FSQ_NP; k++) {
+                xq[k] = wa2[k];
+                double t = q.dg[k] * wa2[k];
+                xs = fsq_fma(t, t, xs);
+            }
+#pragma unroll
+            for (int i = 0; i < FSQ_NPIX; i++) if (live) c.fvec[(size_t)idx * FSQ_NPIX + i] = wa4[i];
+            xnorm = fsq_sqrt(xs);
+            fnorm = fnorm1;
+            niter = niter + 1;
+        }
+        int status = 0;
+        bool c1 = (__builtin_fabs(actred) <= 1e-10) && (prered <= 1e-10) && (0.5 * ratio <= 1);
+        if (c1) status = 1;
+        if (delta <= 1e-10 * xnorm) status = 2;
+        if (c1 && (status == 2)) status = 3;
+        if (status == 0) {
+            if (niter >= 200) status = 5;
+            if ((__builtin_fabs(actred) <= FSQ_MACHEP) && (prered <= FSQ_MACHEP) && (0.5 * ratio <= 1)) status = 6;
+            if (delta <= FSQ_MACHEP * xnorm) status = 7;
+            if (gnorm <= FSQ_MACHEP) status = 8;
+        }
+        if (status == 0 && !accepted) {
+            bool fin = __builtin_isfinite(ratio);
+#pragma unroll
+            for (int k = 0; k < FSQ_NP; k++)
+                fin = fin && __builtin_isfinite(wa1[k]) && __builtin_isfinite(wa2[k]) && __builtin_isfinite(xq[k]);
+            if (!fin) status = -16;
+        }
+        RPH_MARK(5)
+        if (live && status != 0) {
+            FitOut o;
+#pragma unroll
+            for (int k = 0; k < FSQ_NP; k++) o.x[k] = xq[k];
+            o.status = status; o.niter = niter; o.nfev = nfev; o.pad = 0;
+            c.out[idx] = o;
+        }
+        {
+            // accepted -> a new Jacobian (queue A); rejected -> another pass with the same, mutated R (queue B)
+            const bool toA = live && status == 0 && accepted, toB = live && status == 0 && !accepted;
+            const int atA = wave_reserve(cntA_next, toA);
+            const int atB = wave_reserve(cntB_next, toB);
+            if (toA || toB) {
+                double* qn = toA ? (QA_next + atA) : (QB_next + atB);
+                qn[A_IDX * cap] = pack2(idx, 0);
+#pragma unroll
+                for (int k = 0; k < FSQ_NP; k++) { qn[(A_X + k) * cap] = xq[k]; qn[(A_DIAG + k) * cap] = q.dg[k]; }
+                qn[A_LLIM1 * cap] = llim1; qn[A_FNORM * cap] = fnorm; qn[A_PAR * cap] = par; qn[A_DELTA * cap] = delta;
+                qn[A_XNORM * cap] = xnorm; qn[A_ITER * cap] = pack2(niter, nfev);
+                if (toB) {
+                    qn[B_GNORM * cap] = gnorm; qn[B_IPVT * cap] = pack2((int)ipvt, 0);
+#pragma unroll
+                    for (int k = 0; k < FSQ_NP; k++) { qn[(B_QTF + k) * cap] = q.qtf[k]; qn[(B_SDIAG + k) * cap] = q.sdiag[k]; }
+#pragma unroll
+                    for (int i = 0; i < FSQ_NP; i++)
+#pragma unroll
+                        for (int k = i; k < FSQ_NP; k++) qn[(B_R + rpk(i, k)) * cap] = q.r[i][k];
+                }
+            }
+        }
+        RPH_MARK(6)
+    }
+    RPH_FLUSH(0)
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fit-quality metrics and the output row (pflib.py:461-475)
+__global__ void __launch_bounds__(64) kfinish(Ctx c, FsqRow* __restrict__ rows)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.n) return;
+    const FitOut S = c.out[i];
+    double data[FSQ_NPIX], p[FSQ_NP];
+    roi_pixels(c, i, data);
+#pragma unroll
+    for (int k = 0; k < FSQ_NP; k++) p[k] = S.x[k];
+    const double vmax = c.stat[i].vmax, vmean = c.stat[i].vmean;
+    int h = 2, w = 2, field = 0;
+    if (c.from_image) { field = c.cand[3 * i]; h = c.cand[3 * i + 1]; w = c.cand[3 * i + 2]; }
+    double fit[FSQ_NPIX];
+    fsq_model(p, fit);
+    double num = 0.0, den = 0.0, rm = 0.0;
+    for (int k = 0; k < FSQ_NPIX; k++) { double d = data[k] - fit[k]; num += d * d; }
+    for (int k = 0; k < FSQ_NPIX; k++) { double d = data[k] - vmean; den += d * d; }
+    for (int k = 0; k < FSQ_NPIX; k++) rm += fsq_pow2(data[k] - fit[k]);
+    FsqRow r;
+    r.h0 = p[2] + h - 2.5;                                              // pflib.py:461
+    r.w0 = p[3] + w - 2.5;
+    r.H = p[0]; r.A = p[1]; r.sigma_h = p[4]; r.sigma_w = p[5]; r.theta = p[6];
+    r.rmse = fsq_sqrt(rm / 25.0);
+    r.r2 = 1.0 - num / den;
+    {   // pflib.illumina_s_n (pflib.py:261-281)
+        double op[16];
+        int t = 0;
+        for (int ww = 0; ww < 5; ww++) op[t++] = data[ww];
+        for (int ww = 0; ww < 5; ww++) op[t++] = data[20 + ww];
+        for (int hh = 1; hh < 4; hh++) { op[t++] = data[hh * 5]; op[t++] = data[hh * 5 + 4]; }
+        double isum = 0.0;
+        for (int k = 0; k < 16; k++) isum += op[k];
+        double mean = isum / 16.0, rr[8];
+        for (int k = 0; k < 8; k++) { double d0 = op[k] - mean, d1 = op[8 + k] - mean; rr[k] = d0 * d0 + d1 * d1; }
+        double res = ((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7]));
+        res = 0.0 + res;
+        r.s_n = (vmax - mean) / fsq_sqrt(res / 16.0);
+    }
+    r.p2 = p[2]; r.p3 = p[3];
+    r.h = h; r.w = w; r.field = field;
+    const int status = S.status;
+    r.status = status; r.niter = S.niter; r.nfev = S.nfev + (status > 0 ? 1 : 0);   // mpfit's final call (mpfit.py:1353)
+    r.key_h = -1; r.key_w = -1;
+    rows[i] = r;
+}
+
+}  // namespace
+
+#ifdef FSQ_PHASE_PROFILE
+extern "C" int fsq_debug_rphase(unsigned long long* out16, int reset)
+{
+    unsigned long long* p = nullptr;
+    if (hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_rphase)) != hipSuccess) return -1;
+    if (hipMemcpy(out16, p, 16 * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (reset) (void)hipMemset(p, 0, 16 * 8);
+    return 0;
+}
+#endif
+
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" int64_t fsq_fit_workspace_bytes(int64_t n)
+{
+    if (n < 0) return FSQ_EINVAL;
+    const size_t cap = (size_t)n + 64;
+    size_t b = 4096;
+    b += al256(cap * FSQ_NPIX * 8) + al256(cap * sizeof(FitOut)) + al256(cap * sizeof(FitStat));
+    b += 2 * al256(cap * A_LEN * 8) + 2 * al256(cap * B_LEN * 8);
+    return (int64_t)b;
+}
+
+// Host driver of the rounds.  Synchronises the stream every few rounds to read the queue sizes.
+int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_cand, int64_t n, int mode, bool from_image,
+                          FsqRow* d_rows, void* d_ws, int64_t ws_bytes, hipStream_t s)
+{
+    if (ws_bytes < fsq_fit_workspace_bytes(n) || !d_ws) return FSQ_ENOMEM;
+    if (n > 2000000000ll) return FSQ_ENOTIMPL;
+    const size_t cap = (size_t)n + 64;
+    unsigned char* ws = (unsigned char*)d_ws;
+    int* ctl = (int*)ws;                                     // cnt[0..1] queue A (ping/pong), cnt[2..3] queue B
+    size_t o = 4096;
+    Ctx c;
+    c.src = d_src; c.cand = d_cand; c.H = H; c.W = W; c.n = n; c.from_image = from_image ? 1 : 0; c.cap = (long long)cap;
+    c.fvec = (double*)(ws + o); o += al256(cap * FSQ_NPIX * 8);
+    c.out = (FitOut*)(ws + o); o += al256(cap * sizeof(FitOut));
+    c.stat = (FitStat*)(ws + o); o += al256(cap * sizeof(FitStat));
+    double* QA[2]; double* QB[2];
+    QA[0] = (double*)(ws + o); o += al256(cap * A_LEN * 8);
+    QA[1] = (double*)(ws + o); o += al256(cap * A_LEN * 8);
+    QB[0] = (double*)(ws + o); o += al256(cap * B_LEN * 8);
+    QB[1] = (double*)(ws + o); o += al256(cap * B_LEN * 8);
+    int* cA[2] = {ctl + 0, ctl + 1};
+    int* cB[2] = {ctl + 2, ctl + 3};
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int h_init[4] = {(int)n, 0, 0, 0};
+    FSQ_HIP_CHECK(hipMemcpyAsync(ctl, h_init, sizeof(h_init), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(kinit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c, QA[0]);
+    const bool ref = (mode == FSQ_MODE_REF);
+    const long long full = (long long)cus * 8;
+    int h_cnt[4];
+    long long boundA = n, boundB = 0;                        // host-side upper bounds of the queue sizes
+    for (int round = 0;; round++) {
+        const int cur = round & 1, nxt = cur ^ 1;
+        FSQ_HIP_CHECK(hipMemsetAsync(cA[nxt], 0, sizeof(int), s));
+        FSQ_HIP_CHECK(hipMemsetAsync(cB[nxt], 0, sizeof(int), s));
+        long long gA = (boundA + 15) / 16, gB = (boundA + boundB + 63) / 64;
+        if (gA > full) gA = full;
+        if (gB > full) gB = full;
+        if (gA > 0) hipLaunchKernelGGL(kA_jacobian, dim3((unsigned)gA), dim3(64), 0, s, c, QA[cur], cA[cur], QB[cur], cB[cur]);
+        if (gB > 0) {
+            if (ref) hipLaunchKernelGGL(kB_step<true>, dim3((unsigned)gB), dim3(64), 0, s, c, QB[cur], cB[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt]);
+            else hipLaunchKernelGGL(kB_step<false>, dim3((unsigned)gB), dim3(64), 0, s, c, QB[cur], cB[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt]);
+        }
+        boundB = boundA + boundB;                            // every candidate of this round ends in A[nxt], B[nxt] or is done
+        boundA = boundB;
+        if ((round & 3) == 3 || boundB <= 65536) {
+            FSQ_HIP_CHECK(hipMemcpyAsync(h_cnt, ctl, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
+            FSQ_HIP_CHECK(hipStreamSynchronize(s));
+            boundA = h_cnt[nxt];
+            boundB = h_cnt[2 + nxt];
+            if (boundA == 0 && boundB == 0) break;
+        }
+        if (getenv("FSQ_DEBUG_MAX_ROUNDS") && round + 1 >= atoi(getenv("FSQ_DEBUG_MAX_ROUNDS"))) break;
+        if (round > 100000) return FSQ_EHIP;                 // cannot happen: every pass shrinks delta or accepts
+    }
+    hipLaunchKernelGGL(kfinish, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, c, d_rows);
+    FSQ_HIP_CHECK(hipGetLastError());
+    return FSQ_OK;
+}

@@ -314,8 +314,9 @@ FSQ_DEV double quad_lmpar(double* lds, int quad, unsigned ipvt, double delta, do
 
 // ---------------------------------------------------------------------------------------------------
 // Register-resident lmpar / qrsolv: R (logical column order) lives in 49 VGPR pairs, every index is
-// static after unrolling, so one qrsolv is ~28 rotations of pure VALU work with no LDS traffic.
-// Same operations in the same order as quad_lmpar / quad_qrsolv above.
+// static after unrolling, so one qrsolv is ~28 rotations of pure VALU work.  The only memory it touches
+// is a 14-double LDS scratch per fit (STRIDE doubles apart) used to permute 7-vectors between logical
+// and parameter order.  Same operations in the same order as quad_lmpar / quad_qrsolv above.
 struct QuadLm {
     double r[FSQ_NP][FSQ_NP];     // upper triangle = R, diagonal = (possibly aliased) diag, strict lower = S
     double qtf[FSQ_NP];
@@ -340,18 +341,22 @@ FSQ_DEV void quadlm_load(QuadLm& q, const double* lds, int quad, unsigned ipvt)
     }
 }
 
-// scatter a logical-order vector to parameter order through LDS (x[ipvt[j]] = v[j])
-FSQ_DEV void quadlm_scatter(QuadLm& q, double* lds, int quad, unsigned ipvt, const double* v)
+// scatter a logical-order vector to parameter order through the scratch (x[ipvt[j]] = v[j])
+template <int STRIDE>
+FSQ_DEV void quadlm_scatter(QuadLm& q, double* scr, unsigned ipvt, const double* v)
 {
 #pragma unroll
-    for (int j = 0; j < FSQ_NP; j++) QL(Q_XLM, nib_get(ipvt, j)) = v[j];
+    for (int j = 0; j < FSQ_NP; j++) scr[nib_get(ipvt, j) * STRIDE] = v[j];
 #pragma unroll
-    for (int m = 0; m < FSQ_NP; m++) q.xp[m] = QL(Q_XLM, m);
+    for (int m = 0; m < FSQ_NP; m++) q.xp[m] = scr[m * STRIDE];
 }
 
-template <bool ALIASED>
-FSQ_DEV void quadlm_qrsolv(QuadLm& q, double* lds, int quad, unsigned ipvt, double sqrt_par)
+template <bool ALIASED, int STRIDE>
+FSQ_DEV void quadlm_qrsolv(QuadLm& q, double* scr, unsigned ipvt, double sqrt_par)
 {
+    // Branch-free on purpose: the two `break`s of the reference (mpfit.py:1921-1922, 1932-1933) become
+    // select masks, so the 28 rotations form one basic block and independent rotations (row j+1 trails
+    // row j by one column) overlap in the VALU pipeline.
     const int n = FSQ_NP;
     double wa[FSQ_NP], xsave[FSQ_NP];
 #pragma unroll
@@ -360,45 +365,43 @@ FSQ_DEV void quadlm_qrsolv(QuadLm& q, double* lds, int quad, unsigned ipvt, doub
         for (int i = j + 1; i < n; i++) q.r[i][j] = q.r[j][i];
 #pragma unroll
     for (int j = 0; j < n; j++) { xsave[j] = q.r[j][j]; wa[j] = q.qtf[j]; }
-    bool jstop = false;
+    bool jgo = true;                                     // false once `diag[l] == 0: break` has fired
 #pragma unroll
     for (int j = 0; j < n; j++) {
         const double dl = sqrt_par * q.dgp[j];          // (temp * diag)[ipvt[j]]
-        if (dl == 0) jstop = true;
-        if (!jstop) {
+        jgo = jgo && !(dl == 0);
 #pragma unroll
-            for (int k = j; k < n; k++) q.sdiag[k] = 0;
-            q.sdiag[j] = dl;
-            double qtbpj = 0.;
-            bool kstop = false;
+        for (int k = j; k < n; k++) q.sdiag[k] = jgo ? ((k == j) ? dl : 0.0) : q.sdiag[k];
+        double qtbpj = 0.;
+        bool kgo = jgo;                                  // false once `sdiag[k] == 0: break` has fired
 #pragma unroll
-            for (int k = j; k < n; k++) {
-                const double sk = q.sdiag[k];
-                if (sk == 0) kstop = true;
-                if (!kstop) {
-                    const double rkk = q.r[k][k];
-                    const bool cnd = __builtin_fabs(rkk) < __builtin_fabs(sk);
-                    const double num = cnd ? rkk : sk, den = cnd ? sk : rkk;
-                    const double t = num / den;
-                    const double u = 0.5 / fsq_sqrt(.25 + .25 * t * t);
-                    const double v = u * t;
-                    const double cosine = cnd ? v : u, sine = cnd ? u : v;
-                    q.r[k][k] = cosine * rkk + sine * sk;
-                    const double temp = cosine * wa[k] + sine * qtbpj;
-                    qtbpj = -sine * wa[k] + cosine * qtbpj;
-                    wa[k] = temp;
+        for (int k = j; k < n; k++) {
+            const double sk = q.sdiag[k];
+            kgo = kgo && !(sk == 0);
+            const double rkk = q.r[k][k];
+            const bool cnd = __builtin_fabs(rkk) < __builtin_fabs(sk);
+            const double num = cnd ? rkk : sk, den = cnd ? sk : rkk;
+            const double t = num / den;
+            const double u = 0.5 / fsq_sqrt(.25 + .25 * t * t);
+            const double v = u * t;
+            const double cosine = cnd ? v : u, sine = cnd ? u : v;
+            const double nrkk = cosine * rkk + sine * sk;
+            const double temp = cosine * wa[k] + sine * qtbpj;
+            const double nq = -sine * wa[k] + cosine * qtbpj;
+            q.r[k][k] = kgo ? nrkk : rkk;
+            qtbpj = kgo ? nq : qtbpj;
+            wa[k] = kgo ? temp : wa[k];
 #pragma unroll
-                    for (int i = k + 1; i < n; i++) {
-                        const double rik = q.r[i][k], si = q.sdiag[i];
-                        const double tt = cosine * rik + sine * si;
-                        q.sdiag[i] = -sine * rik + cosine * si;
-                        q.r[i][k] = tt;
-                    }
-                }
+            for (int i = k + 1; i < n; i++) {
+                const double rik = q.r[i][k], si = q.sdiag[i];
+                const double tt = cosine * rik + sine * si;
+                const double ns = -sine * rik + cosine * si;
+                q.sdiag[i] = kgo ? ns : si;
+                q.r[i][k] = kgo ? tt : rik;
             }
-            q.sdiag[j] = q.r[j][j];
-            if (!ALIASED) q.r[j][j] = xsave[j];
         }
+        q.sdiag[j] = jgo ? q.r[j][j] : q.sdiag[j];
+        if (!ALIASED) q.r[j][j] = jgo ? xsave[j] : q.r[j][j];
     }
     int nsing = n;
 #pragma unroll
@@ -418,18 +421,19 @@ FSQ_DEV void quadlm_qrsolv(QuadLm& q, double* lds, int quad, unsigned ipvt, doub
             wa[j] = (wa[j] - s) / q.sdiag[j];
         }
     }
-    quadlm_scatter(q, lds, quad, ipvt, wa);
+    quadlm_scatter<STRIDE>(q, scr, ipvt, wa);
     if (ALIASED) {
 #pragma unroll
         for (int m = 0; m < n; m++) q.r[m][m] = q.xp[m];      // x IS numpy.diagonal(r)
     }
 }
 
-// returns par; the step (by parameter index) is left in q.xp AND in LDS Q_XLM; R/sdiag are written back
-template <bool ALIASED>
-FSQ_DEV double quadlm_lmpar(QuadLm& q, double* lds, int quad, unsigned ipvt, double delta, double par)
+// returns par; the step (by parameter index) is left in q.xp; scr = 14 doubles of LDS scratch, STRIDE apart
+template <bool ALIASED, int STRIDE>
+FSQ_DEV double quadlm_lmpar(QuadLm& q, double* scr, unsigned ipvt, double delta, double par)
 {
     const int n = FSQ_NP;
+    double* scr2 = scr + 7 * STRIDE;
     double wa1[FSQ_NP], wa2[FSQ_NP];
     int nsing = n;
     double dmax = __builtin_fabs(q.r[0][0]);
@@ -449,7 +453,7 @@ FSQ_DEV double quadlm_lmpar(QuadLm& q, double* lds, int quad, unsigned ipvt, dou
             for (int i = 0; i < n; i++)
                 if (i < j) wa1[i] = wa1[i] - q.r[i][j] * wa1[j];
         }
-    quadlm_scatter(q, lds, quad, ipvt, wa1);
+    quadlm_scatter<STRIDE>(q, scr, ipvt, wa1);
     double dxnorm = 0.0;
 #pragma unroll
     for (int m = 0; m < n; m++) { double t = q.dg[m] * q.xp[m]; dxnorm = fsq_fma(t, t, dxnorm); }
@@ -495,7 +499,7 @@ FSQ_DEV double quadlm_lmpar(QuadLm& q, double* lds, int quad, unsigned ipvt, dou
     for (int iter = 1;; iter++) {
         if (par == 0) par = np_max2(FSQ_DWARF, paru * 0.001);
         double temp = fsq_sqrt(par);
-        quadlm_qrsolv<ALIASED>(q, lds, quad, ipvt, temp);
+        quadlm_qrsolv<ALIASED, STRIDE>(q, scr, ipvt, temp);
 #pragma unroll
         for (int m = 0; m < n; m++) wa2[m] = q.dg[m] * q.xp[m];
         dxnorm = 0.0;
@@ -505,11 +509,11 @@ FSQ_DEV double quadlm_lmpar(QuadLm& q, double* lds, int quad, unsigned ipvt, dou
         temp = fp;
         fp = dxnorm - delta;
         if ((__builtin_fabs(fp) <= 0.1 * delta) || ((parl == 0) && (fp <= temp) && (temp < 0)) || (iter == 10)) break;
-        // wa1 = diag[ipvt] * wa2[ipvt] / dxnorm : gather wa2 by logical position through LDS
+        // wa1 = diag[ipvt] * wa2[ipvt] / dxnorm : gather wa2 by logical position through the scratch
 #pragma unroll
-        for (int m = 0; m < n; m++) QL(Q_TMP, m) = wa2[m];
+        for (int m = 0; m < n; m++) scr2[m * STRIDE] = wa2[m];
 #pragma unroll
-        for (int j = 0; j < n; j++) wa1[j] = q.dgp[j] * QL(Q_TMP, nib_get(ipvt, j)) / dxnorm;
+        for (int j = 0; j < n; j++) wa1[j] = q.dgp[j] * scr2[nib_get(ipvt, j) * STRIDE] / dxnorm;
 #pragma unroll
         for (int j = 0; j < n - 1; j++) {
             wa1[j] = wa1[j] / q.sdiag[j];

@@ -34,7 +34,8 @@ extern "C" {
 
 #define FSQ_MODE_REF      0 /* reference-faithful fp64 LM (qrsolv/diag(R) aliasing of mpfit.py:1915) */
 #define FSQ_MODE_TEXTBOOK 1 /* same solver with MINPACK's diagonal restore */
-#define FSQ_ENGINE_LANE 0x100 /* OR into mode: one GPU lane per fit instead of a quad of lanes */
+#define FSQ_ENGINE_LANE 0x100 /* OR into mode: persistent kernel, one GPU lane per fit (A/B timing only) */
+#define FSQ_ENGINE_QUAD 0x200 /* OR into mode: persistent kernel, a quad of lanes per fit (A/B timing only) */
 
 /* One fitted candidate: pflib's PSF tuple (pflib.py:475) without the two 5x5 images. 128 bytes. */
 typedef struct FsqRow {
@@ -79,8 +80,10 @@ int fsq_detect(const uint16_t* d_img, int n_fields, int H, int W, const FsqDetec
 int64_t fsq_fit_workspace_bytes(int64_t n);
 
 /* LM-fit n candidates (any mix of fields); d_rows[n] out. Enqueue only.
- * mode: FSQ_MODE_REF / FSQ_MODE_TEXTBOOK, optionally | FSQ_ENGINE_LANE to run the one-lane-per-fit
- * engine instead of the default quad-cooperative one (same results; kept for A/B timing). */
+ * mode: FSQ_MODE_REF / FSQ_MODE_TEXTBOOK.  The default engine advances all candidates in rounds
+ * (Jacobian round / step round, see csrc/fsq_fit_rounds.hip) and synchronises the stream every few
+ * rounds to read the list sizes; | FSQ_ENGINE_LANE or | FSQ_ENGINE_QUAD select the two single-launch
+ * persistent engines instead (identical results; kept for A/B timing). */
 int fsq_fit_candidates(const uint16_t* d_img, int n_fields, int H, int W, const int32_t* d_cand, int64_t n,
                        int mode, FsqRow* d_rows, void* d_workspace, int64_t workspace_bytes, void* stream);
 

@@ -65,7 +65,8 @@ def test_lane_engine_equals_quad_engine(env, name):
     rois = rois_of(img, g["candidates"])
     a = gpu_fit_rois(torch, N, rois, mode=0)
     b = gpu_fit_rois(torch, N, rois, mode=0 | N.ENGINE_LANE)
-    assert a.tobytes() == b.tobytes()
+    c = gpu_fit_rois(torch, N, rois, mode=0 | N.ENGINE_QUAD)
+    assert a.tobytes() == b.tobytes() == c.tobytes()
 
 
 def test_textbook_mode(env):

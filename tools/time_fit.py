@@ -25,3 +25,9 @@ if hasattr(L,'fsq_debug_phase_cycles'):
     for nm,c in zip(names,v[:8]): print('%-12s %6.2f%%'%(nm,100*c/tot))
     print('qlm load %.2f%%  gnorm+diag %.2f%%'%(100*v[10]/(tot+v[10]+v[11]),100*v[11]/(tot+v[10]+v[11])))
     print('inner passes per trip',v[8]/max(v[9],1),'trips',v[9])
+
+if hasattr(L,'fsq_debug_rphase'):
+    buf=(ctypes.c_ulonglong*16)(); L.fsq_debug_rphase(buf,1); v=list(buf)
+    names=['loop/idle','load','lmpar','step logic','trial eval','update logic','store']
+    tot=sum(v[:7])
+    for nm,c in zip(names,v[:7]): print('kB %-12s %6.2f%%'%(nm,100*c/max(tot,1)))
