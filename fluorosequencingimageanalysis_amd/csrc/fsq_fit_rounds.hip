@@ -138,12 +138,14 @@ __global__ void __launch_bounds__(256) kinit(Ctx c, double* __restrict__ QA)
 __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __restrict__ QA, const int* __restrict__ cntA_p,
                                                      double* __restrict__ QB, int* __restrict__ cntB_p)
 {
-    __shared__ double lds[Q_END * 16];
+    __shared__ double lds[Q_KA_END * 16];
     const int lane = threadIdx.x, quad = lane >> 2, c4 = lane & 3, qbase = lane & ~3;
     const int n7 = FSQ_NP;
     const int cntA = *cntA_p;
     double ca[FSQ_NPIX], cb[FSQ_NPIX], refl[FSQ_NPIX];
+    RPH_DECL
     for (int base = blockIdx.x * 16; base < cntA; base += gridDim.x * 16) {
+        RPH_MARK(0)
         const bool active = (base + quad) < cntA;
         const long long cap = c.cap;
         const double* qa = QA + (base + quad);
@@ -171,14 +173,15 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
             for (int k = c4; k < FSQ_NP; k += 4) { QL(Q_X, k) = qa[(A_X + k) * cap]; QL(Q_DIAG, k) = qa[(A_DIAG + k) * cap]; }
         }
         WAVE_SYNC();
+        RPH_MARK(1)
         if (active) {
             // ---- fdjac2 (mpfit.py:1512-1612): slot s = column s of the Jacobian, slot 7 = f(x) itself ---
             double xq[FSQ_NP];
 #pragma unroll
             for (int k = 0; k < FSQ_NP; k++) xq[k] = QL(Q_X, k);
             double hA = 0., hB = 0.;
-#pragma unroll
-            for (int pass = 0; pass < 2; pass++) {
+#pragma unroll 1
+            for (int pass = 0; pass < 2; pass++) {       // rolled on purpose: one copy of the model code (I-cache)
                 const int slot = c4 + 4 * pass;
                 double xp[FSQ_NP];
 #pragma unroll
@@ -196,9 +199,18 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
 #pragma unroll
                     for (int k = 0; k < FSQ_NP; k++) xp[k] = (slot == k) ? (xq[k] + hh) : xq[k];
                 }
-                if (pass == 0) { hA = hh; quad_residual_regs(lds, quad, xp, ca); }
-                else if (slot < 7 || fresh) { hB = hh; quad_residual_regs(lds, quad, xp, cb); }
+                quad_residual_regs(lds, quad, xp, refl);          // refl is free here: used as the staging column
+                if (pass == 0) {
+                    hA = hh;
+#pragma unroll
+                    for (int i = 0; i < FSQ_NPIX; i++) ca[i] = refl[i];
+                } else {
+                    hB = hh;
+#pragma unroll
+                    for (int i = 0; i < FSQ_NPIX; i++) cb[i] = refl[i];
+                }
             }
+            RPH_MARK(2)
             if (fresh) {                    // mpfit's first function call (mpfit.py:999): fvec = f(x0)
                 if (c4 == 3) {
 #pragma unroll
@@ -242,6 +254,7 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                     if (pegB) cb[i] = 0;
                 }
             }
+            RPH_MARK(3)
             // ---- qrfac with column pivoting (mpfit.py:1748-1822), Q^T f fused in as slot 7 ----------
             {
                 double nA = fsq_sqrt(dot_regcol(ca, 25));
@@ -327,6 +340,7 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                 for (int i = 0; i + 1 < FSQ_NPIX; i++) { ca[i] = ca[i + 1]; cb[i] = cb[i + 1]; }
                 WAVE_SYNC();
             }
+            RPH_MARK(4)
             // ---- first iteration scaling, gradient test (mpfit.py:1099-1160) -----------------------
             if (niter == 1) {
 #pragma unroll
@@ -357,6 +371,7 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
 #pragma unroll
                 for (int k = 0; k < FSQ_NP; k++) { double dg = QL(Q_DIAG, k), an = QL(Q_ACN, k); QL(Q_DIAG, k) = (dg > an) ? dg : an; }
             }
+            RPH_MARK(5)
             // ---- finish it (gradient test) ... ---------------------------------------------------------------
             if (status != 0 && c4 == 0) {
                 FitOut o;
@@ -392,7 +407,9 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                 }
             }
         }
+        RPH_MARK(6)
     }
+    RPH_FLUSH(8)
 }
 
 // ---------------------------------------------------------------------------------------------------

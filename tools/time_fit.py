@@ -31,3 +31,8 @@ if hasattr(L,'fsq_debug_rphase'):
     names=['loop/idle','load','lmpar','step logic','trial eval','update logic','store']
     tot=sum(v[:7])
     for nm,c in zip(names,v[:7]): print('kB %-12s %6.2f%%'%(nm,100*c/max(tot,1)))
+
+    names=['loop/idle','load','J evals','diff+peg','qrfac','gnorm etc','handover']
+    tot=sum(v[8:15])
+    for nm,c in zip(names,v[8:15]): print('kA %-12s %6.2f%%'%(nm,100*c/max(tot,1)))
+    print('kA total / kB total cycles: %.2f'%(tot/max(sum(v[:7]),1)))
