@@ -43,7 +43,7 @@ def cpu_baseline(imgs, cand, counts, offsets, n_threads):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     O.build()
-    n_fields = min(8, len(imgs))
+    n_fields = min(24, len(imgs))          # ~100k LM solves: about 30 s of single-core CPU work
     n = int(offsets[n_fields])
     c = cand[:n]
     rois = np.stack([imgs[f, h - 2:h + 3, w - 2:w + 3] for f, h, w in c]).reshape(-1, 25)
@@ -147,14 +147,17 @@ def main():
                        "fields_per_gpu": a.fields, "candidates_per_gpu": int(total),
                        "parallelism": "fields sharded over %d rank(s), RCCL p2p gather of peak tables" % world},
             "fields_per_sec": a.fields * world * a.steps / dt,
-            "roofline": {"bound": "valu-fp64 (no MFMA, ~1 GB/s of HBM: neither hbm nor mfma bounds this kernel)",
-                         "kernel": "fsq_fit_cand_kernel", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS,
+            "roofline": {"bound": "valu-fp64 (the LM solve is vector-ALU work: no MFMA-shaped contraction and ~40 GB/s of HBM, "
+                                  "so neither 'hbm' nor 'mfma' bounds it - see DESIGN.md)",
+                         "kernel": "LM fit = kinit + rounds of (kA_jacobian, kB_step) + kfinish, timed as one unit",
+                         "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
                          "launch_ms": fit_avg_ms, "fits_per_launch": int(total), "flop_per_fit": FLOP_PER_FIT},
         }
         if not a.no_cpu_baseline:
             cand, counts, offsets = eng.candidates(total)
-            out["cpu_baseline"] = cpu_baseline(imgs, cand, counts, offsets, os.cpu_count() or 1)
+            n_thr = min(16, len(os.sched_getaffinity(0)))     # the box's CPU share for one GPU
+            out["cpu_baseline"] = cpu_baseline(imgs, cand, counts, offsets, n_thr)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -12,5 +12,3 @@ extern "C" int fsq_device_count(void)
     return n;
 }
 
-// ---- temporary stub (replaced when fsq_register.hip lands) ----
-extern "C" int fsq_phase_correlate(const double*, const double*, int, int, int, int, double*, void*) { return FSQ_ENOTIMPL; }

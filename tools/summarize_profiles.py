@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output of tools/collect_profiles.sh into gpurun_out/<round>/summary.{md,json}."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+base = "gpurun_out/%s" % R
+out = {"round": R}
+md = ["# rocprofv3 summary (%s): python3 bench.py --steps 3 --warmup 1" % R, ""]
+f = glob.glob(base + "/stats/*/*kernel_stats.csv")
+if f:
+    rows = list(csv.DictReader(open(f[0])))
+    md += ["| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
+    ks = []
+    for r in rows[:14]:
+        ks.append({"name": r["Name"], "calls": int(r["Calls"]), "total_ms": float(r["TotalDurationNs"]) / 1e6,
+                   "avg_us": float(r["AverageNs"]) / 1e3, "pct": float(r["Percentage"])})
+        md.append("| `%s` | %s | %.2f | %.1f | %s |" % (r["Name"][:80], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                     float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    out["kernel_stats"] = ks
+for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    f = glob.glob(base + "/%s/*/*counter_collection.csv" % tag)
+    if not f:
+        continue
+    acc = collections.defaultdict(float)
+    for r in csv.DictReader(open(f[0])):
+        if r["Counter_Name"] == ctr:
+            name = r["Kernel_Name"]
+            key = "kA_jacobian" if "kA_jacobian" in name else "kB_step" if "kB_step" in name else \
+                  "k1_response" if "k1_response" in name else "other"
+            acc[key] += float(r["Counter_Value"])
+    out[ctr + "_KiB_256_fields_1_step"] = dict(acc)
+if "FETCH_SIZE_KiB_256_fields_1_step" in out and "WRITE_SIZE_KiB_256_fields_1_step" in out:
+    fe, wr = out["FETCH_SIZE_KiB_256_fields_1_step"], out["WRITE_SIZE_KiB_256_fields_1_step"]
+    # MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950; WRITE_SIZE is exact. Units KiB.
+    fit_bytes = (2 * (fe.get("kA_jacobian", 0) + fe.get("kB_step", 0)) + wr.get("kA_jacobian", 0) + wr.get("kB_step", 0)) * 1024
+    out["fit_kernel_hbm_bytes_per_launch"] = fit_bytes * 4       # scaled from 256 to the 1024 fields of one bench step
+    md += ["", "HBM traffic of the LM fit (kA_jacobian + kB_step, all rounds of one step, 256-field run scaled x4 to the "
+           "1024-field step; FETCH_SIZE doubled per MI355X_MICROARCH.md): %.1f GB" % (out["fit_kernel_hbm_bytes_per_launch"] / 1e9)]
+json.dump(out, open(base + "/summary.json", "w"), indent=1)
+open(base + "/summary.md", "w").write("\n".join(md) + "\n")
+print("\n".join(md))
