@@ -80,6 +80,77 @@ FSQ_DEV double fsq_exp_core(double x, double xtail)
 
 FSQ_DEV double fsq_exp(double x) { return fsq_exp_core<false>(x, 0.0); }
 
+// Branch-free exp for |x| < 512 (and exact for tiny / huge / non-finite x): the same operations as
+// fsq_exp_core on its main path, with the rare paths folded in by selects so that 25 pixels form ONE basic
+// block (independent dependency chains overlap in the VALU pipeline).  512 <= |x| < 1024 would need the
+// subnormal/overflow fix-up of e_exp.c's specialcase(): the LM model never gets there (sigma >= 0.75 and
+// centres in [2,3] bound the exponent by 64), so that range only raises *bad and the caller redoes the fit
+// with fsq_exp.
+FSQ_DEV double fsq_exp_bf(double x, bool* bad)
+{
+    const unsigned abstop = (unsigned)(fsq_bits(x) >> 52) & 0x7ff;
+    const bool tiny = (abstop - 0x3c9u) >= 0x80000000u;            // |x| < 2^-54 (incl. +-0)
+    const bool big = abstop >= 0x409u;                             // |x| >= 1024, inf, nan
+    *bad = *bad || (abstop == 0x408u);
+    double kd = fsq_fma(x, EXP_INVLN2N, EXP_SHIFT);
+    unsigned long long ki = fsq_bits(kd);
+    kd -= EXP_SHIFT;
+    double r = fsq_fma(kd, EXP_NEGLN2HIN, x);
+    r = fsq_fma(kd, EXP_NEGLN2LON, r);
+    unsigned idx = 2u * ((unsigned)ki & 127u);
+    unsigned long long top = ki << 45;
+    double tail = fsq_dbl(FSQ_EXP_TAB[idx]);
+    unsigned long long sbits = FSQ_EXP_TAB[idx + 1] + top;
+    double r2 = r * r;
+    double p23 = fsq_fma(EXP_C3, r, EXP_C2);
+    double p45 = fsq_fma(r, EXP_C5, EXP_C4);
+    double t = r + tail;
+    double tmp = fsq_fma(p23, r2, t);
+    tmp = fsq_fma(r2 * r2, p45, tmp);
+    double scale = fsq_dbl(sbits);
+    double res = fsq_fma(scale, tmp, scale);
+    const double res_big = (x != x) ? (1.0 + x) : ((fsq_bits(x) >> 63) ? 0.0 : __builtin_inf());
+    res = tiny ? (1.0 + x) : res;
+    res = big ? res_big : res;
+    return res;
+}
+
+// ---- division by a shared divisor --------------------------------------------------------------------------
+// The compiler expands every fp64 `n / d` into v_div_scale x2, v_rcp, 4 Newton fmas, mul, fma, v_div_fmas,
+// v_div_fixup (13 instructions, one quarter-rate).  When v_div_scale does not rescale (VCC = 0, operands passed
+// through) that sequence is rcp + 4 fma on d alone, then mul / fma / fma on n, then v_div_fixup: so for a divisor
+// shared by many numerators the d-only part is hoisted (fsq_divisor) and every quotient costs 4 instructions
+// (fsq_div_by) and is bit-identical to `n / d`.  v_div_scale rescales only when d is denormal or huge, the quotient
+// is denormal, exponent(n) - exponent(d) >= 768, or n is tiny (biased exponent <= 53); zeros / inf / nan never
+// reach the arithmetic result because v_div_fixup overrides it from (d, n) alone.  Callers keep d within
+// 2^+-FSQ_DIV_ED and non-zero finite n within 2^+-FSQ_DIV_EN (exponents tracked with fsq_expo, zero/inf/nan -> 0)
+// and send a fit whose values leave those ranges through the plain `/` build of the kernel instead.
+#define FSQ_DIV_ED 250
+#define FSQ_DIV_EN 500
+struct FsqDivisor { double d, r; };
+FSQ_DEV int fsq_expo(double v) { return __builtin_amdgcn_frexp_exp(v); }
+FSQ_DEV FsqDivisor fsq_divisor(double d)
+{
+    FsqDivisor k;
+    k.d = d;
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fsq_fma(-d, r, 1.0);
+    r = fsq_fma(r, e, r);
+    e = fsq_fma(-d, r, 1.0);
+    k.r = fsq_fma(r, e, r);
+    return k;
+}
+FSQ_DEV bool fsq_divisor_in_range(double d) { return (unsigned)(fsq_expo(d) + FSQ_DIV_ED) <= 2u * FSQ_DIV_ED; }
+FSQ_DEV double fsq_div_by(double n, const FsqDivisor& k)
+{
+    double q = n * k.r;
+    double rem = fsq_fma(-k.d, q, n);
+    q = fsq_fma(rem, k.r, q);
+    return __builtin_amdgcn_div_fixup(q, k.d, n);
+}
+// FAST = false: the plain division (same call sites, used by the exact build of a kernel)
+template <bool FAST> FSQ_DEV double fsq_div_sel(double n, const FsqDivisor& k) { return FAST ? fsq_div_by(n, k) : n / k.d; }
+
 // ---- pow(x, 2.0) (e_pow.c): what numpy computes for a float64 SCALAR ** 2 ---------------------
 __device__ __noinline__ double fsq_pow2(double x)
 {

@@ -157,8 +157,8 @@ __global__ void __launch_bounds__(64, 1) k3_quad(const uint16_t* __restrict__ sr
 #pragma unroll
                     for (int k = 0; k < FSQ_NP; k++) xp[k] = (slot == k) ? (xq[k] + hh) : xq[k];
                 }
-                if (pass == 0) { hA = hh; quad_residual_regs(lds, quad, xp, ca); }
-                else if (slot < 7 || fresh) { hB = hh; quad_residual_regs(lds, quad, xp, cb); }
+                if (pass == 0) { hA = hh; quad_residual_regs<false>(lds, quad, xp, ca, nullptr, nullptr); }
+                else if (slot < 7 || fresh) { hB = hh; quad_residual_regs<false>(lds, quad, xp, cb, nullptr, nullptr); }
             }
             PH_MARK(1)
             if (fresh) {                    // mpfit's first function call (mpfit.py:999): fvec = f(x0)

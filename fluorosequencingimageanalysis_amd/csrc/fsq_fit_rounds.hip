@@ -62,6 +62,8 @@ struct Ctx {
     FitOut* out;              // [n]
     FitStat* stat;            // [n]
     long long cap;            // queue capacity (positions)
+    int* slow_total;          // statistics: fits that went through the plain-division kernel
+    int force_slow_mod;       // debug: route every fit with idx % mod == 0 through the plain-division kernel
 };
 
 // Reserve one queue slot for every lane with `want` set: one atomic per wave (a single counter saturates at
@@ -135,20 +137,29 @@ __global__ void __launch_bounds__(256) kinit(Ctx c, double* __restrict__ QA)
 
 // ---------------------------------------------------------------------------------------------------
 // kA: Jacobian round.  block = 64 threads = 16 quads, grid-stride over list A.
+// FAST = true: divisions by a shared divisor go through fsq_div_by (fsq_devmath.h) and every operand range that
+// makes it bit-identical to `/` is checked on the way; a quad that leaves those ranges writes nothing and appends
+// its queue position to `slow`, which the FAST = false build (plain divisions, same code) works off next.
+template <bool FAST>
 __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __restrict__ QA, const int* __restrict__ cntA_p,
-                                                     double* __restrict__ QB, int* __restrict__ cntB_p)
+                                                     double* __restrict__ QB, int* __restrict__ cntB_p,
+                                                     int* __restrict__ slow, int* __restrict__ slow_cnt)
 {
     __shared__ double lds[Q_KA_END * 16];
     const int lane = threadIdx.x, quad = lane >> 2, c4 = lane & 3, qbase = lane & ~3;
     const int n7 = FSQ_NP;
-    const int cntA = *cntA_p;
+    const int cntA = FAST ? *cntA_p : *slow_cnt;
+    if (!FAST && blockIdx.x == 0 && threadIdx.x == 0 && cntA > 0) atomicAdd(c.slow_total, cntA);
     double ca[FSQ_NPIX], cb[FSQ_NPIX], refl[FSQ_NPIX];
     RPH_DECL
     for (int base = blockIdx.x * 16; base < cntA; base += gridDim.x * 16) {
         RPH_MARK(0)
         const bool active = (base + quad) < cntA;
         const long long cap = c.cap;
-        const double* qa = QA + (base + quad);
+        const int qpos = FAST ? (base + quad) : (active ? slow[base + quad] : 0);
+        const double* qa = QA + qpos;
+        bool hz = false, qhz = false;     // FAST: some operand left the range in which fsq_div_by == `/`
+        int emin = 0;                     // FAST: smallest exponent among the tracked numerators
         int idx = 0;
         double llim1 = 0., fnorm = 0., xnorm = 0., delta = 0., par_in = 0.;
         int niter = 1, nfev = 0;
@@ -199,7 +210,7 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
 #pragma unroll
                     for (int k = 0; k < FSQ_NP; k++) xp[k] = (slot == k) ? (xq[k] + hh) : xq[k];
                 }
-                quad_residual_regs(lds, quad, xp, refl);          // refl is free here: used as the staging column
+                quad_residual_regs<FAST>(lds, quad, xp, refl, &emin, &hz);   // refl is free here: the staging column
                 if (pass == 0) {
                     hA = hh;
 #pragma unroll
@@ -224,11 +235,20 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
             bool pegA = false, pegB = false;
             {
                 double sA = 0.0, sB = 0.0;
+                const FsqDivisor kA_ = fsq_divisor(hA), kB_ = fsq_divisor(hB);     // hB = 0 in lane 3: quotient unused
+                if (FAST) {
+                    hz = hz || !fsq_divisor_in_range(hA) || !fsq_divisor_in_range(hB);
+                    // residuals are bounded by 2^16 + x0 + x1, so the numerators below stay under 2^102
+                    hz = hz || !(xq[0] <= 0x1p100) || !(xq[1] <= 0x1p100);
+                }
 #pragma unroll
                 for (int i = 0; i < FSQ_NPIX; i++) {
                     double fv = QL(Q_FVEC, i);
-                    ca[i] = (ca[i] - fv) / hA;
-                    if (c4 < 3) cb[i] = (cb[i] - fv) / hB; else cb[i] = fv;
+                    double nA_ = ca[i] - fv, nB_ = cb[i] - fv;
+                    if (FAST) { emin = min(emin, fsq_expo(nA_)); emin = min(emin, fsq_expo(nB_)); }
+                    ca[i] = fsq_div_sel<FAST>(nA_, kA_);
+                    double qB_ = fsq_div_sel<FAST>(nB_, kB_);
+                    cb[i] = (c4 < 3) ? qB_ : fv;
                     sA += fv * ca[i];
                     sB += fv * cb[i];
                 }
@@ -289,19 +309,30 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
 #pragma unroll
                 for (int i = 0; i < FSQ_NPIX; i++) refl[i] = quad_bcast(useB ? cb[i] : ca[i], owner);
                 double ajj0;
+                int emin_s = 0;                                     // FAST: lower bound of the scaled reflector's exponents
                 if (!broken) {
                     double ajnorm = fsq_sqrt(dot_regcol(refl, len));
                     if (ajnorm == 0) broken = true;                 // mpfit.py:1790 `break`
                     else {
                         if (refl[0] < 0) ajnorm = -ajnorm;
+                        const FsqDivisor kn = fsq_divisor(ajnorm);
+                        if (FAST) {
+                            int er = 0;
 #pragma unroll
-                        for (int i = 0; i < FSQ_NPIX; i++)
-                            if (i < len) refl[i] = refl[i] / ajnorm;
+                            for (int i = 0; i < FSQ_NPIX; i++) er = min(er, fsq_expo(refl[i]));
+                            emin = min(emin, er);                   // |refl[i]| <= |ajnorm|: no upper check needed
+                            hz = hz || !fsq_divisor_in_range(ajnorm);
+                            emin_s = er - fsq_expo(ajnorm) - 1;
+                        }
+#pragma unroll
+                        for (int i = 0; i < FSQ_NPIX; i++) refl[i] = fsq_div_sel<FAST>(refl[i], kn);   // rows >= len are zeros
                         refl[0] = refl[0] + 1;
                         QL(Q_TMP, 0) = -ajnorm;
                     }
                 }
                 ajj0 = refl[0];
+                const FsqDivisor kj = fsq_divisor(ajj0);
+                if (FAST) hz = hz || !fsq_divisor_in_range(ajj0);
 #pragma unroll
                 for (int pass = 0; pass < 2; pass++) {
                     const int slot = c4 + 4 * pass;
@@ -311,12 +342,16 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                     const bool todo = is_f ? true : (!broken && k > j);
                     if (todo && ajj0 != 0) {
                         double s = 0.0;
+                        // rows >= len hold zeros (see the shift below): they add +0 to the sum and stay zero in
+                        // the update, so neither loop needs a bound check and both are straight-line code
 #pragma unroll
-                        for (int i = 0; i < FSQ_NPIX; i++)
-                            if (i < len) s += col[i] * refl[i];
+                        for (int i = 0; i < FSQ_NPIX; i++) s += col[i] * refl[i];
+                        if (FAST) {     // numerators refl[i] * s: |refl[i]| < 4, exponent >= emin_s (or zero)
+                            const int es = fsq_expo(s);
+                            hz = hz || (emin_s + es - 2 < -FSQ_DIV_EN) || (es + 2 > FSQ_DIV_EN);
+                        }
 #pragma unroll
-                        for (int i = 0; i < FSQ_NPIX; i++)
-                            if (i < len) col[i] = col[i] - (refl[i] * s) / ajj0;
+                        for (int i = 0; i < FSQ_NPIX; i++) col[i] = col[i] - fsq_div_sel<FAST>(refl[i] * s, kj);
                         if (!is_f) {
                             double rk = QL(Q_RDIAG, k);
                             if (rk != 0) {
@@ -338,6 +373,7 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                 QL(Q_R, j * 7 + lj) = QL(Q_RDIAG, j);               // fjac[j, lj] = rdiag[j] (mpfit.py:1123)
 #pragma unroll
                 for (int i = 0; i + 1 < FSQ_NPIX; i++) { ca[i] = ca[i + 1]; cb[i] = cb[i + 1]; }
+                ca[FSQ_NPIX - 1] = 0.0; cb[FSQ_NPIX - 1] = 0.0;
                 WAVE_SYNC();
             }
             RPH_MARK(4)
@@ -373,7 +409,14 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
             }
             RPH_MARK(5)
             // ---- finish it (gradient test) ... ---------------------------------------------------------------
-            if (status != 0 && c4 == 0) {
+            if (FAST) {
+                // one verdict per quad: any lane out of range sends the whole fit to the plain-division kernel
+                hz = hz || (emin < -FSQ_DIV_EN);
+                if (c.force_slow_mod > 0 && (idx % c.force_slow_mod) == 0) hz = true;
+                const unsigned long long m = __ballot(hz);
+                qhz = ((m >> qbase) & 0xfull) != 0;
+            }
+            if (status != 0 && c4 == 0 && !qhz) {
                 FitOut o;
 #pragma unroll
                 for (int k = 0; k < FSQ_NP; k++) o.x[k] = QL(Q_X, k);
@@ -383,7 +426,12 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
         }
         // ---- ... or hand it over to the step round: one queue-B slot per surviving quad -------------------------
         {
-            const bool go = active && (status == 0);
+            bool go = active && (status == 0);
+            if (FAST) {
+                int sat = wave_reserve(slow_cnt, qhz && c4 == 0);
+                if (qhz && c4 == 0) slow[sat] = base + quad;
+                go = go && !qhz;
+            }
             int at = wave_reserve(cntB_p, go && c4 == 0);
             at = __shfl(at, qbase);
             if (go) {
@@ -681,6 +729,38 @@ __global__ void __launch_bounds__(64) kfinish(Ctx c, FsqRow* __restrict__ rows)
 
 }  // namespace
 
+// ---- self-test hook: fsq_div_by against the compiler's `/` on caller-supplied operand pairs ------------------
+namespace {
+__global__ void kdivcheck(const double* __restrict__ num, const double* __restrict__ den, long long n, unsigned long long* bad)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a = num[i], d = den[i];
+    const FsqDivisor k = fsq_divisor(d);
+    const double q0 = a / d, q1 = fsq_div_by(a, k);
+    if (fsq_bits(q0) != fsq_bits(q1)) atomicAdd(bad, 1ull);
+}
+long long g_last_slow = 0;
+}  // namespace
+
+extern "C" int fsq_selftest_division(const double* d_num, const double* d_den, int64_t n, int64_t* mismatches, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (!d_num || !d_den || !mismatches || n < 0) return FSQ_EINVAL;
+    unsigned long long* d_bad = nullptr;
+    FSQ_HIP_CHECK(hipMalloc((void**)&d_bad, 8));
+    FSQ_HIP_CHECK(hipMemsetAsync(d_bad, 0, 8, s));
+    if (n > 0) hipLaunchKernelGGL(kdivcheck, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_num, d_den, (long long)n, d_bad);
+    unsigned long long h = 0;
+    FSQ_HIP_CHECK(hipMemcpyAsync(&h, d_bad, 8, hipMemcpyDeviceToHost, s));
+    FSQ_HIP_CHECK(hipStreamSynchronize(s));
+    (void)hipFree(d_bad);
+    *mismatches = (int64_t)h;
+    return FSQ_OK;
+}
+
+extern "C" int64_t fsq_fit_last_slow_count(void) { return g_last_slow; }
+
 #ifdef FSQ_PHASE_PROFILE
 extern "C" int fsq_debug_rphase(unsigned long long* out16, int reset)
 {
@@ -700,7 +780,7 @@ extern "C" int64_t fsq_fit_workspace_bytes(int64_t n)
     const size_t cap = (size_t)n + 64;
     size_t b = 4096;
     b += al256(cap * FSQ_NPIX * 8) + al256(cap * sizeof(FitOut)) + al256(cap * sizeof(FitStat));
-    b += 2 * al256(cap * A_LEN * 8) + 2 * al256(cap * B_LEN * 8);
+    b += 2 * al256(cap * A_LEN * 8) + 2 * al256(cap * B_LEN * 8) + al256(cap * sizeof(int));
     return (int64_t)b;
 }
 
@@ -712,7 +792,7 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
     if (n > 2000000000ll) return FSQ_ENOTIMPL;
     const size_t cap = (size_t)n + 64;
     unsigned char* ws = (unsigned char*)d_ws;
-    int* ctl = (int*)ws;                                     // cnt[0..1] queue A (ping/pong), cnt[2..3] queue B
+    int* ctl = (int*)ws;                                     // per ping/pong set: {queue A, queue B, slow list, pad}
     size_t o = 4096;
     Ctx c;
     c.src = d_src; c.cand = d_cand; c.H = H; c.W = W; c.n = n; c.from_image = from_image ? 1 : 0; c.cap = (long long)cap;
@@ -724,25 +804,35 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
     QA[1] = (double*)(ws + o); o += al256(cap * A_LEN * 8);
     QB[0] = (double*)(ws + o); o += al256(cap * B_LEN * 8);
     QB[1] = (double*)(ws + o); o += al256(cap * B_LEN * 8);
-    int* cA[2] = {ctl + 0, ctl + 1};
-    int* cB[2] = {ctl + 2, ctl + 3};
+    int* cA[2] = {ctl + 0, ctl + 4};
+    int* cB[2] = {ctl + 1, ctl + 5};
+    int* cS[2] = {ctl + 2, ctl + 6};
+    int* slow = (int*)(ws + o); o += al256(cap * sizeof(int));
+    {
+        const char* e = getenv("FSQ_DEBUG_FORCE_SLOW");
+        c.force_slow_mod = e ? atoi(e) : 0;
+    }
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    int h_init[4] = {(int)n, 0, 0, 0};
+    int h_init[12] = {(int)n, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    c.slow_total = ctl + 8;
     FSQ_HIP_CHECK(hipMemcpyAsync(ctl, h_init, sizeof(h_init), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(kinit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c, QA[0]);
     const bool ref = (mode == FSQ_MODE_REF);
     const long long full = (long long)cus * 8;
-    int h_cnt[4];
+    int h_cnt[12];
     long long boundA = n, boundB = 0;                        // host-side upper bounds of the queue sizes
     for (int round = 0;; round++) {
         const int cur = round & 1, nxt = cur ^ 1;
-        FSQ_HIP_CHECK(hipMemsetAsync(cA[nxt], 0, sizeof(int), s));
-        FSQ_HIP_CHECK(hipMemsetAsync(cB[nxt], 0, sizeof(int), s));
+        FSQ_HIP_CHECK(hipMemsetAsync(cA[nxt], 0, 4 * sizeof(int), s));      // A, B and slow counters of the next set
         long long gA = (boundA + 15) / 16, gB = (boundA + boundB + 63) / 64;
         if (gA > full) gA = full;
         if (gB > full) gB = full;
-        if (gA > 0) hipLaunchKernelGGL(kA_jacobian, dim3((unsigned)gA), dim3(64), 0, s, c, QA[cur], cA[cur], QB[cur], cB[cur]);
+        if (gA > 0) {
+            hipLaunchKernelGGL(kA_jacobian<true>, dim3((unsigned)gA), dim3(64), 0, s, c, QA[cur], cA[cur], QB[cur], cB[cur], slow, cS[cur]);
+            // the plain-division build drains the (normally empty) slow list: its blocks leave at once when it is
+            hipLaunchKernelGGL(kA_jacobian<false>, dim3((unsigned)(gA < 128 ? gA : 128)), dim3(64), 0, s, c, QA[cur], cA[cur], QB[cur], cB[cur], slow, cS[cur]);
+        }
         if (gB > 0) {
             if (ref) hipLaunchKernelGGL(kB_step<true>, dim3((unsigned)gB), dim3(64), 0, s, c, QB[cur], cB[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt]);
             else hipLaunchKernelGGL(kB_step<false>, dim3((unsigned)gB), dim3(64), 0, s, c, QB[cur], cB[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt]);
@@ -752,8 +842,9 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
         if ((round & 3) == 3 || boundB <= 65536) {
             FSQ_HIP_CHECK(hipMemcpyAsync(h_cnt, ctl, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
             FSQ_HIP_CHECK(hipStreamSynchronize(s));
-            boundA = h_cnt[nxt];
-            boundB = h_cnt[2 + nxt];
+            boundA = h_cnt[4 * nxt];
+            boundB = h_cnt[4 * nxt + 1];
+            g_last_slow = h_cnt[8];
             if (boundA == 0 && boundB == 0) break;
         }
         if (getenv("FSQ_DEBUG_MAX_ROUNDS") && round + 1 >= atoi(getenv("FSQ_DEBUG_MAX_ROUNDS"))) break;

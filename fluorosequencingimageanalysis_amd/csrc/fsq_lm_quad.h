@@ -37,19 +37,30 @@ FSQ_DEV unsigned nib_set(unsigned w, int k, int v) { return (w & ~(15u << (4 * k
 
 FSQ_DEV double quad_bcast(double v, int src_lane) { return __shfl(v, src_lane); }
 
-// OpenBLAS strided ddot pattern on a register column of `len` valid rows (positions 0..len-1)
+// OpenBLAS strided ddot pattern on a register column of `len` valid rows (positions 0..len-1), 19 <= len <= 25
+// (the qrfac of a 25x7 system).  Branch-free: the group-of-4 / scalar-tail decision of the BLAS kernel is made
+// with selects, so the call sits inside one basic block.
 FSQ_DEV double dot_regcol(const double* x, int len)
 {
+    __builtin_assume(len >= 19 && len <= 25);
     double t1 = 0.0, t2 = 0.0;
 #pragma unroll
     for (int s = 0; s < 7; s++) {
-        if (4 * s + 3 < len) {
+        if (4 * s + 3 < 19) {
             t2 += fsq_fma(x[4 * s + 1], x[4 * s + 1], x[4 * s + 3] * x[4 * s + 3]);
             t1 += fsq_fma(x[4 * s], x[4 * s], x[4 * s + 2] * x[4 * s + 2]);
         } else {
+            const bool full = (4 * s + 3 < len);
+            double g1 = t1;
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                if (4 * s + r < 25 && 4 * s + r < len) t1 = fsq_fma(x[4 * s + r], x[4 * s + r], t1);
+                if (4 * s + r < 25) { double f = fsq_fma(x[4 * s + r], x[4 * s + r], g1); g1 = (4 * s + r < len) ? f : g1; }
+            if (4 * s + 3 < 25) {
+                double f2 = t2 + fsq_fma(x[4 * s + 1], x[4 * s + 1], x[4 * s + 3] * x[4 * s + 3]);
+                double f1 = t1 + fsq_fma(x[4 * s], x[4 * s], x[4 * s + 2] * x[4 * s + 2]);
+                t2 = full ? f2 : t2;
+                t1 = full ? f1 : g1;
+            } else t1 = g1;
         }
     }
     return t2 + t1;
@@ -57,29 +68,50 @@ FSQ_DEV double dot_regcol(const double* x, int len)
 // same pattern starting one row lower (enorm(a[j+1:, lk]) of the norm re-computation)
 FSQ_DEV double dot_regcol_from1(const double* x, int len)
 {
+    __builtin_assume(len >= 19 && len <= 25);
     double t1 = 0.0, t2 = 0.0;
     const int n = len - 1;
 #pragma unroll
     for (int s = 0; s < 6; s++) {
-        if (4 * s + 3 < n) {
+        if (4 * s + 3 < 18) {
             t2 += fsq_fma(x[4 * s + 2], x[4 * s + 2], x[4 * s + 4] * x[4 * s + 4]);
             t1 += fsq_fma(x[4 * s + 1], x[4 * s + 1], x[4 * s + 3] * x[4 * s + 3]);
         } else {
+            const bool full = (4 * s + 3 < n);
+            double g1 = t1;
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                if (4 * s + r + 1 < 25 && 4 * s + r < n) t1 = fsq_fma(x[4 * s + r + 1], x[4 * s + r + 1], t1);
+                if (4 * s + r + 1 < 25) { double f = fsq_fma(x[4 * s + r + 1], x[4 * s + r + 1], g1); g1 = (4 * s + r < n) ? f : g1; }
+            if (4 * s + 4 < 25) {
+                double f2 = t2 + fsq_fma(x[4 * s + 2], x[4 * s + 2], x[4 * s + 4] * x[4 * s + 4]);
+                double f1 = t1 + fsq_fma(x[4 * s + 1], x[4 * s + 1], x[4 * s + 3] * x[4 * s + 3]);
+                t2 = full ? f2 : t2;
+                t1 = full ? f1 : g1;
+            } else t1 = g1;
         }
     }
     return t2 + t1;
 }
 
-// model residuals data - g at parameters p, all 25 pixels into registers (data read from LDS)
-FSQ_DEV void quad_residual_regs(const double* lds, int quad, const double* p, double* r)
+// model residuals data - g at parameters p, all 25 pixels into registers (data read from LDS).
+// FAST: the two divisions per pixel share their divisors (sigma_h, sigma_w) -> fsq_div_by, exp is the branch-free
+// fsq_exp_bf; *emin collects the smallest numerator exponent and *hz is raised when a divisor, the centre or an exp
+// argument leaves the range those are exact in (the caller then repeats the fit with FAST = false).
+template <bool FAST>
+FSQ_DEV void quad_residual_regs(const double* lds, int quad, const double* p, double* r, int* emin, bool* hz)
 {
+    bool bad = false;
     double s, c;
     fsq_sincos(FSQ_PI_180 * p[6], &s, &c);
     const double rcen_x = p[3] * c - p[2] * s;
     const double rcen_y = p[3] * s + p[2] * c;
+    const FsqDivisor k4 = fsq_divisor(p[4]), k5 = fsq_divisor(p[5]);
+    int em = 0;
+    if (FAST) {
+        // |numerator| <= |p2| + |p3| + 8: bounded once the centre is
+        *hz = *hz || !fsq_divisor_in_range(p[4]) || !fsq_divisor_in_range(p[5]) || !(__builtin_fabs(p[2]) <= 0x1p100) ||
+              !(__builtin_fabs(p[3]) <= 0x1p100);
+    }
 #pragma unroll
     for (int xi = 0; xi < 5; xi++)
 #pragma unroll
@@ -87,12 +119,15 @@ FSQ_DEV void quad_residual_regs(const double* lds, int quad, const double* p, do
             double x = (double)xi, y = (double)yi;
             double xp = x * c - y * s;
             double yp = x * s + y * c;
-            double u = (rcen_x - xp) / p[4];
-            double v = (rcen_y - yp) / p[5];
+            double nu = rcen_x - xp, nv = rcen_y - yp;
+            if (FAST) { em = min(em, fsq_expo(nu)); em = min(em, fsq_expo(nv)); }
+            double u = fsq_div_sel<FAST>(nu, k4);
+            double v = fsq_div_sel<FAST>(nv, k5);
             double e = -(u * u + v * v) / 2.;
-            double g = p[0] + p[1] * fsq_exp(e);
+            double g = p[0] + p[1] * (FAST ? fsq_exp_bf(e, &bad) : fsq_exp(e));
             r[xi * 5 + yi] = QL(Q_DATA, xi * 5 + yi) - g;
         }
+    if (FAST) { *emin = min(*emin, em); *hz = *hz || bad; }
 }
 
 // trial-point residuals: the 25 pixels are split over the 4 lanes of the quad, results go to LDS

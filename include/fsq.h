@@ -118,6 +118,17 @@ int fsq_fit_images(const FsqRow* d_rows, const int32_t* d_idx, int64_t n, double
 int fsq_phase_correlate(const double* d_ref, const double* d_reg, int n_pairs, int H, int W,
                         int upsample_factor, double* d_out4, void* stream);
 
+/*
+ * Self-test hooks of the LM fit (no reference counterpart).
+ * fsq_selftest_division: the fit kernel divides by shared divisors through a hoisted reciprocal that is
+ *   bit-identical to the compiler's fp64 division inside a guarded operand range (fsq_devmath.h); this counts
+ *   the operand pairs (d_num[i], d_den[i]) for which the two differ.  Synchronises the stream.
+ * fsq_fit_last_slow_count: number of fits of the last fsq_fit_* call that left the guarded range and were
+ *   redone by the plain-division build of the kernel (env FSQ_DEBUG_FORCE_SLOW=k forces idx % k == 0 there).
+ */
+int fsq_selftest_division(const double* d_num, const double* d_den, int64_t n, int64_t* mismatches, void* stream);
+int64_t fsq_fit_last_slow_count(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,3 +77,52 @@ def test_textbook_mode(env):
     ref = O.fit_rois(rois, mode=1)
     p = np.stack([got[k] for k in ("H", "A", "p2", "p3", "sigma_h", "sigma_w", "theta")], axis=1)
     assert bits_equal(p, ref["p"]).all()
+
+
+def test_hoisted_division_is_bit_identical_inside_its_guarded_range(env):
+    """fsq_div_by (shared-divisor division of the Jacobian kernel) vs the compiler's `/`: random mantissas with
+    |d| in 2^[-250, 250], |n| in 2^[-500, 500], both signs, plus zeros / inf / nan numerators and divisors."""
+    import ctypes
+    torch, N, O = env
+    rng = np.random.default_rng(1234)
+    n = 1 << 22
+    def rnd(emax, size):
+        m = rng.random(size) + 1.0
+        e = rng.integers(-emax, emax, size)
+        s = rng.choice([-1.0, 1.0], size)
+        return s * np.ldexp(m, e)
+    num, den = rnd(499, n), rnd(249, n)
+    # ties and exact quotients, small integers (what pixel data produce), the range edges, specials
+    k = 1 << 18
+    num[:k] = rng.integers(-70000, 70000, k).astype(np.float64)
+    den[:k] = rng.integers(1, 4096, k).astype(np.float64)
+    num[k:2 * k] = np.ldexp(rng.random(k) + 1.0, rng.choice([-500, -499, 499, 500], k))
+    den[2 * k:3 * k] = np.ldexp(rng.random(k) + 1.0, rng.choice([-250, -249, 249, 250], k))
+    specials = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -3.0])
+    sn, sd = np.meshgrid(specials, specials)
+    num[3 * k:3 * k + sn.size] = sn.ravel()
+    den[3 * k:3 * k + sd.size] = sd.ravel()
+    num[3 * k + 100:3 * k + 100 + specials.size] = specials       # specials over ordinary divisors
+    dn, dd = torch.from_numpy(num).cuda(), torch.from_numpy(den).cuda()
+    bad = ctypes.c_int64(-1)
+    N.check(N.lib().fsq_selftest_division(dn.data_ptr(), dd.data_ptr(), n, ctypes.byref(bad),
+                                          torch.cuda.current_stream().cuda_stream), "selftest")
+    assert bad.value == 0
+
+
+def test_plain_division_kernel_gives_the_same_fits(env, monkeypatch):
+    """Every third fit is forced through the FAST = false build of the Jacobian kernel (the route a fit takes when
+    an operand leaves the guarded range): results stay bit-identical to the oracle."""
+    torch, N, O = env
+    g, img = load_field("f3_hard_256")
+    rois = rois_of(img, g["candidates"])
+    monkeypatch.setenv("FSQ_DEBUG_FORCE_SLOW", "3")
+    got = gpu_fit_rois(torch, N, rois)
+    assert N.lib().fsq_fit_last_slow_count() > 0
+    monkeypatch.delenv("FSQ_DEBUG_FORCE_SLOW")
+    p = np.stack([got[k] for k in ("H", "A", "p2", "p3", "sigma_h", "sigma_w", "theta")], axis=1)
+    assert bits_equal(p, g["params"]).all()
+    assert np.array_equal(got["status"], g["status"])
+    got2 = gpu_fit_rois(torch, N, rois)
+    assert N.lib().fsq_fit_last_slow_count() == 0, "ordinary data must never leave the fast path"
+    assert got2.tobytes() == got.tobytes()
