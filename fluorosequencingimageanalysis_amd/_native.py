@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libfsq_hip.so")
+LIB_PATH = os.environ.get("FSQ_HIP_LIB") or os.path.join(HERE, "csrc", "libfsq_hip.so")   # env: A/B builds
 
 FSQ_OK, FSQ_EINVAL, FSQ_ENOMEM, FSQ_ERANGE, FSQ_EHIP, FSQ_EASSERT, FSQ_ENOTIMPL = 0, -1, -2, -3, -4, -5, -6
 MODE_REF, MODE_TEXTBOOK, ENGINE_LANE, ENGINE_QUAD = 0, 1, 0x100, 0x200

@@ -115,6 +115,42 @@ FSQ_DEV double fsq_exp_bf(double x, bool* bad)
     return res;
 }
 
+// The same function in two halves around its table look-up, so that a caller can start the look-ups of several
+// arguments (from an LDS copy of the table) before finishing any of them.
+struct FsqExpA { double x, r; unsigned long long ki; };
+FSQ_DEV unsigned fsq_exp_bf_a(double x, FsqExpA* a)      // returns the table index (in 8-byte units, even)
+{
+    double kd = fsq_fma(x, EXP_INVLN2N, EXP_SHIFT);
+    a->x = x;
+    a->ki = fsq_bits(kd);
+    kd -= EXP_SHIFT;
+    double r = fsq_fma(kd, EXP_NEGLN2HIN, x);
+    a->r = fsq_fma(kd, EXP_NEGLN2LON, r);
+    return 2u * ((unsigned)a->ki & 127u);
+}
+FSQ_DEV double fsq_exp_bf_b(const FsqExpA& a, unsigned long long tab_tail, unsigned long long tab_sbits, bool* bad)
+{
+    const double x = a.x, r = a.r;
+    const unsigned abstop = (unsigned)(fsq_bits(x) >> 52) & 0x7ff;
+    const bool tiny = (abstop - 0x3c9u) >= 0x80000000u;
+    const bool big = abstop >= 0x409u;
+    *bad = *bad || (abstop == 0x408u);
+    double tail = fsq_dbl(tab_tail);
+    unsigned long long sbits = tab_sbits + (a.ki << 45);
+    double r2 = r * r;
+    double p23 = fsq_fma(EXP_C3, r, EXP_C2);
+    double p45 = fsq_fma(r, EXP_C5, EXP_C4);
+    double t = r + tail;
+    double tmp = fsq_fma(p23, r2, t);
+    tmp = fsq_fma(r2 * r2, p45, tmp);
+    double scale = fsq_dbl(sbits);
+    double res = fsq_fma(scale, tmp, scale);
+    const double res_big = (x != x) ? (1.0 + x) : ((fsq_bits(x) >> 63) ? 0.0 : __builtin_inf());
+    res = tiny ? (1.0 + x) : res;
+    res = big ? res_big : res;
+    return res;
+}
+
 // ---- division by a shared divisor --------------------------------------------------------------------------
 // The compiler expands every fp64 `n / d` into v_div_scale x2, v_rcp, 4 Newton fmas, mul, fma, v_div_fmas,
 // v_div_fixup (13 instructions, one quarter-rate).  When v_div_scale does not rescale (VCC = 0, operands passed

@@ -58,6 +58,7 @@ struct FitStat {              // by candidate: ROI statistics (kinit)
 
 struct Ctx {
     const uint16_t* src; const int32_t* cand; int H, W; long long n; int from_image;
+    uint16_t* roi;            // [n][32]: the 25 pixels of every ROI, gathered once by kinit (64 bytes per fit)
     double* fvec;             // [n][25]
     FitOut* out;              // [n]
     FitStat* stat;            // [n]
@@ -99,12 +100,33 @@ FSQ_DEV void roi_pixels(const Ctx& c, long long idx, double* d)
     }
 }
 
+// the 25 pixels of fit idx from the compact copy (one 64-byte line instead of five image rows)
+FSQ_DEV void roi_compact(const Ctx& c, long long idx, double* d)
+{
+    const uint4* src = (const uint4*)(c.roi + (size_t)idx * 32);
+    const uint4 a = src[0], b = src[1], e = src[2], f = src[3];
+    const unsigned w[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, e.x, e.y, e.z, e.w, f.x, f.y, f.z, f.w};
+#pragma unroll
+    for (int k = 0; k < FSQ_NPIX; k++) d[k] = (double)((w[k >> 1] >> (16 * (k & 1))) & 0xffffu);
+}
+
 __global__ void __launch_bounds__(256) kinit(Ctx c, double* __restrict__ QA)
 {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c.n) return;
     double v[FSQ_NPIX];
     roi_pixels(c, i, v);
+    {
+        unsigned w[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            unsigned lo = (2 * k < FSQ_NPIX) ? (unsigned)v[2 * k] : 0u, hi = (2 * k + 1 < FSQ_NPIX) ? (unsigned)v[2 * k + 1] : 0u;
+            w[k] = lo | (hi << 16);
+        }
+        uint4* dst = (uint4*)(c.roi + (size_t)i * 32);
+        dst[0] = make_uint4(w[0], w[1], w[2], w[3]); dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        dst[2] = make_uint4(w[8], w[9], w[10], w[11]); dst[3] = make_uint4(w[12], w[13], w[14], w[15]);
+    }
     double mx = v[0], isum = 0.0;
 #pragma unroll
     for (int k = 0; k < FSQ_NPIX; k++) { mx = v[k] > mx ? v[k] : mx; isum += v[k]; }
@@ -174,11 +196,14 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
             llim1 = qa[A_LLIM1 * cap]; fnorm = qa[A_FNORM * cap]; par_in = qa[A_PAR * cap]; delta = qa[A_DELTA * cap];
             xnorm = qa[A_XNORM * cap];
             fresh = (nfev == 0);
-            {
-                double d[FSQ_NPIX];
-                roi_pixels(c, idx, d);
+            {   // lane c4 of the quad converts pixels 8*c4 .. 8*c4+7 of the compact ROI copy
+                const uint4 pw = *(const uint4*)(c.roi + (size_t)idx * 32 + c4 * 8);
+                const unsigned w[4] = {pw.x, pw.y, pw.z, pw.w};
 #pragma unroll
-                for (int k = 0; k < FSQ_NPIX; k++) QL(Q_DATA, k) = d[k];
+                for (int t = 0; t < 8; t++) {
+                    const int k = c4 * 8 + t;
+                    if (k < FSQ_NPIX) QL(Q_DATA, k) = (double)((w[t >> 1] >> (16 * (t & 1))) & 0xffffu);
+                }
             }
             if (!fresh) for (int k = c4; k < FSQ_NPIX; k += 4) QL(Q_FVEC, k) = c.fvec[(size_t)idx * FSQ_NPIX + k];
             for (int k = c4; k < FSQ_NP; k += 4) { QL(Q_X, k) = qa[(A_X + k) * cap]; QL(Q_DIAG, k) = qa[(A_DIAG + k) * cap]; }
@@ -497,7 +522,7 @@ __global__ void __launch_bounds__(64, 1) kB_step(Ctx c, const double* __restrict
         const double llim1 = qb[A_LLIM1 * cap], gnorm = qb[B_GNORM * cap];
         double fnorm = qb[A_FNORM * cap], par = qb[A_PAR * cap], delta = qb[A_DELTA * cap], xnorm = qb[A_XNORM * cap], fnorm1;
         double data[FSQ_NPIX];
-        roi_pixels(c, idx, data);
+        roi_compact(c, idx, data);
 #pragma unroll
         for (int k = 0; k < FSQ_NP; k++) myscr[k * 64] = q.dg[k];
 #pragma unroll
@@ -687,7 +712,7 @@ __global__ void __launch_bounds__(64) kfinish(Ctx c, FsqRow* __restrict__ rows)
     if (i >= c.n) return;
     const FitOut S = c.out[i];
     double data[FSQ_NPIX], p[FSQ_NP];
-    roi_pixels(c, i, data);
+    roi_compact(c, i, data);
 #pragma unroll
     for (int k = 0; k < FSQ_NP; k++) p[k] = S.x[k];
     const double vmax = c.stat[i].vmax, vmean = c.stat[i].vmean;
@@ -779,7 +804,7 @@ extern "C" int64_t fsq_fit_workspace_bytes(int64_t n)
     if (n < 0) return FSQ_EINVAL;
     const size_t cap = (size_t)n + 64;
     size_t b = 4096;
-    b += al256(cap * FSQ_NPIX * 8) + al256(cap * sizeof(FitOut)) + al256(cap * sizeof(FitStat));
+    b += al256(cap * 64) + al256(cap * FSQ_NPIX * 8) + al256(cap * sizeof(FitOut)) + al256(cap * sizeof(FitStat));
     b += 2 * al256(cap * A_LEN * 8) + 2 * al256(cap * B_LEN * 8) + al256(cap * sizeof(int));
     return (int64_t)b;
 }
@@ -796,6 +821,7 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
     size_t o = 4096;
     Ctx c;
     c.src = d_src; c.cand = d_cand; c.H = H; c.W = W; c.n = n; c.from_image = from_image ? 1 : 0; c.cap = (long long)cap;
+    c.roi = (uint16_t*)(ws + o); o += al256(cap * 64);
     c.fvec = (double*)(ws + o); o += al256(cap * FSQ_NPIX * 8);
     c.out = (FitOut*)(ws + o); o += al256(cap * sizeof(FitOut));
     c.stat = (FitStat*)(ws + o); o += al256(cap * sizeof(FitStat));

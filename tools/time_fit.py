@@ -36,3 +36,5 @@ if hasattr(L,'fsq_debug_rphase'):
     tot=sum(v[8:15])
     for nm,c in zip(names,v[8:15]): print('kA %-12s %6.2f%%'%(nm,100*c/max(tot,1)))
     print('kA total / kB total cycles: %.2f'%(tot/max(sum(v[:7]),1)))
+    passes=float(r['niter'].sum())*3
+    print('kA ticks per wave-pass (16 fits): %.0f   kB ticks per wave-pass (64 fits): %.0f'%(tot/(passes/16), sum(v[:7])/(passes/64)))
