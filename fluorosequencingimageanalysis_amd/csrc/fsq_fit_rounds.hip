@@ -193,9 +193,7 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
             int dummy;
             unpack2(qa[A_IDX * cap], &idx, &dummy);
             unpack2(qa[A_ITER * cap], &niter, &nfev);
-            llim1 = qa[A_LLIM1 * cap]; fnorm = qa[A_FNORM * cap]; par_in = qa[A_PAR * cap]; delta = qa[A_DELTA * cap];
-            xnorm = qa[A_XNORM * cap];
-            fresh = (nfev == 0);
+            fresh = (nfev == 0);        // llim1 goes to LDS below; fnorm, par, delta, xnorm are fetched when first needed
             {   // lane c4 of the quad converts pixels 8*c4 .. 8*c4+7 of the compact ROI copy
                 const uint4 pw = *(const uint4*)(c.roi + (size_t)idx * 32 + c4 * 8);
                 const unsigned w[4] = {pw.x, pw.y, pw.z, pw.w};
@@ -207,33 +205,30 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
             }
             if (!fresh) for (int k = c4; k < FSQ_NPIX; k += 4) QL(Q_FVEC, k) = c.fvec[(size_t)idx * FSQ_NPIX + k];
             for (int k = c4; k < FSQ_NP; k += 4) { QL(Q_X, k) = qa[(A_X + k) * cap]; QL(Q_DIAG, k) = qa[(A_DIAG + k) * cap]; }
+            if (c4 == 0) QL(Q_TMP, 6) = qa[A_LLIM1 * cap];
         }
         WAVE_SYNC();
         RPH_MARK(1)
         if (active) {
             // ---- fdjac2 (mpfit.py:1512-1612): slot s = column s of the Jacobian, slot 7 = f(x) itself ---
-            double xq[FSQ_NP];
-#pragma unroll
-            for (int k = 0; k < FSQ_NP; k++) xq[k] = QL(Q_X, k);
             double hA = 0., hB = 0.;
 #pragma unroll 1
             for (int pass = 0; pass < 2; pass++) {       // rolled on purpose: one copy of the model code (I-cache)
                 const int slot = c4 + 4 * pass;
-                double xp[FSQ_NP];
+                asm volatile("" ::: "memory");      // keep the pixel reads inside the pass (hoisted they cost 50 VGPRs)
+                double xp[FSQ_NP];          // x is re-read from LDS where needed rather than kept in registers
 #pragma unroll
-                for (int k = 0; k < FSQ_NP; k++) xp[k] = xq[k];
+                for (int k = 0; k < FSQ_NP; k++) xp[k] = QL(Q_X, k);
                 double hh = 0.;
                 if (slot < 7) {
-                    double xs = xq[0];
-#pragma unroll
-                    for (int k = 1; k < FSQ_NP; k++) xs = (slot == k) ? xq[k] : xs;
+                    const double xs = QL(Q_X, slot);
                     const double eps = 1.4901161193847656e-08;
                     hh = eps * __builtin_fabs(xs);
                     if (hh == 0) hh = eps;
                     double ul = slot < 2 ? 0.0 : slot < 4 ? 3.0 : slot < 6 ? 2.0 : 360.0;
                     if (slot >= 2 && (xs > ul - hh)) hh = -hh;
 #pragma unroll
-                    for (int k = 0; k < FSQ_NP; k++) xp[k] = (slot == k) ? (xq[k] + hh) : xq[k];
+                    for (int k = 0; k < FSQ_NP; k++) xp[k] = (slot == k) ? (xp[k] + hh) : xp[k];
                 }
                 quad_residual_regs<FAST>(lds, quad, xp, refl, &emin, &hz);   // refl is free here: the staging column
                 if (pass == 0) {
@@ -256,7 +251,7 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
             }
             WAVE_SYNC();
             nfev += 7;
-            if (fresh) fnorm = fsq_sqrt(lds_dot25(lds, quad, Q_FVEC));
+            if (fresh) QL(Q_TMP, 5) = fsq_sqrt(lds_dot25(lds, quad, Q_FVEC));     // fnorm of a fresh fit
             bool pegA = false, pegB = false;
             {
                 double sA = 0.0, sB = 0.0;
@@ -264,7 +259,7 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                 if (FAST) {
                     hz = hz || !fsq_divisor_in_range(hA) || !fsq_divisor_in_range(hB);
                     // residuals are bounded by 2^16 + x0 + x1, so the numerators below stay under 2^102
-                    hz = hz || !(xq[0] <= 0x1p100) || !(xq[1] <= 0x1p100);
+                    hz = hz || !(QL(Q_X, 0) <= 0x1p100) || !(QL(Q_X, 1) <= 0x1p100);
                 }
 #pragma unroll
                 for (int i = 0; i < FSQ_NPIX; i++) {
@@ -279,17 +274,13 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                 }
                 {   // pegged parameters (mpfit.py:1073-1091)
                     const int slot = c4;
-                    double xs = xq[0];
-#pragma unroll
-                    for (int k = 1; k < FSQ_NP; k++) xs = (slot == k) ? xq[k] : xs;
+                    const double xs = QL(Q_X, slot), llim1 = QL(Q_TMP, 6);
                     bool lp = (xs == fsq_llim(slot, llim1)), up = fsq_qulim(slot) && (xs == fsq_ulim(slot));
                     pegA = (lp && sA > 0) || (up && sA < 0);
                 }
                 if (c4 < 3) {
                     const int slot = c4 + 4;
-                    double xs = xq[4];
-#pragma unroll
-                    for (int k = 5; k < FSQ_NP; k++) xs = (slot == k) ? xq[k] : xs;
+                    const double xs = QL(Q_X, slot), llim1 = QL(Q_TMP, 6);
                     bool lp = (xs == fsq_llim(slot, llim1)), up = (xs == fsq_ulim(slot));
                     pegB = (lp && sB > 0) || (up && sB < 0);
                 }
@@ -331,31 +322,43 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                 const int lj = nib_get(ipvt, j);
                 const int owner = qbase + (lj & 3);
                 const bool useB = (lj >> 2) != 0;
-#pragma unroll
-                for (int i = 0; i < FSQ_NPIX; i++) refl[i] = quad_bcast(useB ? cb[i] : ca[i], owner);
-                double ajj0;
+                // The lane that owns the pivot column turns it into the Householder vector and publishes it in LDS
+                // (the Q_DATA slots: the pixels are not needed again in this pass); the other lanes of the quad read
+                // it from there, so no lane keeps a third 25-row column in registers.
                 int emin_s = 0;                                     // FAST: lower bound of the scaled reflector's exponents
-                if (!broken) {
-                    double ajnorm = fsq_sqrt(dot_regcol(refl, len));
-                    if (ajnorm == 0) broken = true;                 // mpfit.py:1790 `break`
-                    else {
-                        if (refl[0] < 0) ajnorm = -ajnorm;
-                        const FsqDivisor kn = fsq_divisor(ajnorm);
-                        if (FAST) {
-                            int er = 0;
+                bool brk = false;
+                if (lane == owner) {
+                    double t[FSQ_NPIX];
 #pragma unroll
-                            for (int i = 0; i < FSQ_NPIX; i++) er = min(er, fsq_expo(refl[i]));
-                            emin = min(emin, er);                   // |refl[i]| <= |ajnorm|: no upper check needed
-                            hz = hz || !fsq_divisor_in_range(ajnorm);
-                            emin_s = er - fsq_expo(ajnorm) - 1;
+                    for (int i = 0; i < FSQ_NPIX; i++) t[i] = useB ? cb[i] : ca[i];
+                    if (!broken) {
+                        double ajnorm = fsq_sqrt(dot_regcol(t, len));
+                        if (ajnorm == 0) brk = true;                // mpfit.py:1790 `break`
+                        else {
+                            if (t[0] < 0) ajnorm = -ajnorm;
+                            const FsqDivisor kn = fsq_divisor(ajnorm);
+                            if (FAST) {
+                                int er = 0;
+#pragma unroll
+                                for (int i = 0; i < FSQ_NPIX; i++) er = min(er, fsq_expo(t[i]));
+                                emin = min(emin, er);               // |t[i]| <= |ajnorm|: no upper check needed
+                                hz = hz || !fsq_divisor_in_range(ajnorm);
+                                emin_s = er - fsq_expo(ajnorm) - 1;
+                            }
+#pragma unroll
+                            for (int i = 0; i < FSQ_NPIX; i++) t[i] = fsq_div_sel<FAST>(t[i], kn);   // rows >= len are zeros
+                            t[0] = t[0] + 1;
+                            QL(Q_TMP, 0) = -ajnorm;
                         }
-#pragma unroll
-                        for (int i = 0; i < FSQ_NPIX; i++) refl[i] = fsq_div_sel<FAST>(refl[i], kn);   // rows >= len are zeros
-                        refl[0] = refl[0] + 1;
-                        QL(Q_TMP, 0) = -ajnorm;
                     }
+#pragma unroll
+                    for (int i = 0; i < FSQ_NPIX; i++) QL(Q_DATA, i) = t[i];
                 }
-                ajj0 = refl[0];
+                WAVE_SYNC();
+                broken = broken || (__shfl((int)brk, owner) != 0);
+                emin_s = __shfl(emin_s, owner);
+#define REFL(i) QL(Q_DATA, i)
+                const double ajj0 = REFL(0);
                 const FsqDivisor kj = fsq_divisor(ajj0);
                 if (FAST) hz = hz || !fsq_divisor_in_range(ajj0);
 #pragma unroll
@@ -370,13 +373,13 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                         // rows >= len hold zeros (see the shift below): they add +0 to the sum and stay zero in
                         // the update, so neither loop needs a bound check and both are straight-line code
 #pragma unroll
-                        for (int i = 0; i < FSQ_NPIX; i++) s += col[i] * refl[i];
-                        if (FAST) {     // numerators refl[i] * s: |refl[i]| < 4, exponent >= emin_s (or zero)
+                        for (int i = 0; i < FSQ_NPIX; i++) s += col[i] * REFL(i);
+                        if (FAST) {     // numerators REFL(i) * s: |REFL(i)| < 4, exponent >= emin_s (or zero)
                             const int es = fsq_expo(s);
                             hz = hz || (emin_s + es - 2 < -FSQ_DIV_EN) || (es + 2 > FSQ_DIV_EN);
                         }
 #pragma unroll
-                        for (int i = 0; i < FSQ_NPIX; i++) col[i] = col[i] - fsq_div_sel<FAST>(refl[i] * s, kj);
+                        for (int i = 0; i < FSQ_NPIX; i++) col[i] = col[i] - fsq_div_sel<FAST>(REFL(i) * s, kj);
                         if (!is_f) {
                             double rk = QL(Q_RDIAG, k);
                             if (rk != 0) {
@@ -403,6 +406,8 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
             }
             RPH_MARK(4)
             // ---- first iteration scaling, gradient test (mpfit.py:1099-1160) -----------------------
+            llim1 = qa[A_LLIM1 * cap]; par_in = qa[A_PAR * cap]; delta = qa[A_DELTA * cap]; xnorm = qa[A_XNORM * cap];
+            fnorm = fresh ? QL(Q_TMP, 5) : qa[A_FNORM * cap];
             if (niter == 1) {
 #pragma unroll
                 for (int k = 0; k < FSQ_NP; k++) {
