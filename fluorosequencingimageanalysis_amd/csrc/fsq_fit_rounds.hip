@@ -42,11 +42,14 @@ __device__ unsigned long long g_rphase[16];
 // records with fully coalesced loads; a fit's live state travels with it from queue to queue:
 //   queue A record (input of kA):  idx | x[7] | diag[7] | llim1 fnorm par delta xnorm | niter,nfev      21 x 8 B
 //   queue B record (input of kB):  the same 21 + gnorm | ipvt | qtf[7] | sdiag[7] | R upper[28]          65 x 8 B
+//   queue C record (kB, resumed):  the same 65 + parl paru fp | lmpar iterations done                    69 x 8 B
 // Indexed by candidate: fvec[25] (written on acceptance, read by kA), the final result, the ROI statistics.
 // The ROI pixels are re-read from the image (5 rows of 10 B) - they never change.
 enum { A_IDX = 0, A_X = 1, A_DIAG = 8, A_LLIM1 = 15, A_FNORM = 16, A_PAR = 17, A_DELTA = 18, A_XNORM = 19, A_ITER = 20,
        A_LEN = 21,
-       B_GNORM = 21, B_IPVT = 22, B_QTF = 23, B_SDIAG = 30, B_R = 37, B_LEN = 65 };
+       B_GNORM = 21, B_IPVT = 22, B_QTF = 23, B_SDIAG = 30, B_R = 37, B_LEN = 65,
+       // a fit parked in the middle of lmpar (queue C): the B record as it stands plus the Newton state on par
+       C_PARL = 65, C_PARU = 66, C_FP = 67, C_LMIT = 68, C_LEN = 69 };
 
 struct FitOut {               // by candidate: final parameters (written at termination)
     double x[FSQ_NP];
@@ -492,10 +495,18 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
 
 // ---------------------------------------------------------------------------------------------------
 // kB: step round.  One lane per fit, grid-stride over list B.
-template <bool ALIASED>
+// lmpar's Newton iteration on par takes 1 iteration for half of the fits and all 10 for a quarter of them; a wave
+// would always wait for its slowest lane.  RESUME = false therefore stops after FSQ_LMPAR_FIRST iterations and parks
+// the lanes that are not done in queue C (their R / sdiag / par state as it stands); RESUME = true picks those up,
+// finishes lmpar and runs the same step logic.  Lanes of a resumed wave nearly all need the full 10 iterations.
+#ifndef FSQ_LMPAR_FIRST
+#define FSQ_LMPAR_FIRST 3
+#endif
+template <bool ALIASED, bool RESUME>
 __global__ void __launch_bounds__(64, 1) kB_step(Ctx c, const double* __restrict__ QB, const int* __restrict__ cntB_p,
                                                   double* __restrict__ QA_next, int* __restrict__ cntA_next,
-                                                  double* __restrict__ QB_next, int* __restrict__ cntB_next)
+                                                  double* __restrict__ QB_next, int* __restrict__ cntB_next,
+                                                  double* __restrict__ QC, int* __restrict__ cntC)
 {
     __shared__ double scr[21 * 64];
     const int lane = threadIdx.x;
@@ -504,7 +515,7 @@ __global__ void __launch_bounds__(64, 1) kB_step(Ctx c, const double* __restrict
     RPH_DECL
     for (int base = blockIdx.x * 64; base < cntB; base += gridDim.x * 64) {
         RPH_MARK(0)
-        const bool live = (base + lane) < cntB;
+        bool live = (base + lane) < cntB;
         const int slot_in = live ? (base + lane) : 0;
         const long long cap = c.cap;
         const double* qb = QB + slot_in;
@@ -534,7 +545,43 @@ __global__ void __launch_bounds__(64, 1) kB_step(Ctx c, const double* __restrict
         for (int j = 0; j < FSQ_NP; j++) q.dgp[j] = myscr[nib_get(ipvt, j) * 64];
 
         RPH_MARK(1)
-        par = quadlm_lmpar<ALIASED, 64>(q, myscr, ipvt, delta, par);
+        {
+            QuadLmparSt st;
+            if (!RESUME) {
+                quadlm_lmpar_begin<ALIASED, 64>(q, myscr, ipvt, delta, par, st);
+                quadlm_lmpar_run<ALIASED, 64>(q, myscr, ipvt, delta, st, FSQ_LMPAR_FIRST);
+            } else {
+                int it, dm;
+                unpack2(qb[C_LMIT * cap], &it, &dm);
+                st.par = par; st.parl = qb[C_PARL * cap]; st.paru = qb[C_PARU * cap]; st.fp = qb[C_FP * cap];
+                st.iter = it; st.done = false;
+                quadlm_lmpar_run<ALIASED, 64>(q, myscr, ipvt, delta, st, 10);
+            }
+            par = st.par;
+            if (!RESUME) {
+                const bool park = live && !st.done;
+                const int atC = wave_reserve(cntC, park);
+                if (park) {
+                    double* qn = QC + atC;
+                    qn[A_IDX * cap] = pack2(idx, 0);
+#pragma unroll
+                    for (int k = 0; k < FSQ_NP; k++) {
+                        qn[(A_X + k) * cap] = xq[k]; qn[(A_DIAG + k) * cap] = q.dg[k];
+                        qn[(B_QTF + k) * cap] = q.qtf[k]; qn[(B_SDIAG + k) * cap] = q.sdiag[k];
+                    }
+                    qn[A_LLIM1 * cap] = llim1; qn[A_FNORM * cap] = fnorm; qn[A_PAR * cap] = par; qn[A_DELTA * cap] = delta;
+                    qn[A_XNORM * cap] = xnorm; qn[A_ITER * cap] = pack2(niter, nfev);
+                    qn[B_GNORM * cap] = gnorm; qn[B_IPVT * cap] = pack2((int)ipvt, 0);
+#pragma unroll
+                    for (int i = 0; i < FSQ_NP; i++)
+#pragma unroll
+                        for (int k = i; k < FSQ_NP; k++) qn[(B_R + rpk(i, k)) * cap] = q.r[i][k];
+                    qn[C_PARL * cap] = st.parl; qn[C_PARU * cap] = st.paru; qn[C_FP * cap] = st.fp;
+                    qn[C_LMIT * cap] = pack2(st.iter, 0);
+                }
+                live = live && !park;           // a parked lane idles through the rest of this pass
+            }
+        }
         RPH_MARK(2)
         double wa1[FSQ_NP], wa2[FSQ_NP];
         bool lpeg[FSQ_NP], upeg[FSQ_NP];
@@ -810,7 +857,7 @@ extern "C" int64_t fsq_fit_workspace_bytes(int64_t n)
     const size_t cap = (size_t)n + 64;
     size_t b = 4096;
     b += al256(cap * 64) + al256(cap * FSQ_NPIX * 8) + al256(cap * sizeof(FitOut)) + al256(cap * sizeof(FitStat));
-    b += 2 * al256(cap * A_LEN * 8) + 2 * al256(cap * B_LEN * 8) + al256(cap * sizeof(int));
+    b += 2 * al256(cap * A_LEN * 8) + 2 * al256(cap * B_LEN * 8) + al256(cap * C_LEN * 8) + al256(cap * sizeof(int));
     return (int64_t)b;
 }
 
@@ -838,6 +885,8 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
     int* cA[2] = {ctl + 0, ctl + 4};
     int* cB[2] = {ctl + 1, ctl + 5};
     int* cS[2] = {ctl + 2, ctl + 6};
+    int* cC[2] = {ctl + 3, ctl + 7};
+    double* QC = (double*)(ws + o); o += al256(cap * C_LEN * 8);
     int* slow = (int*)(ws + o); o += al256(cap * sizeof(int));
     {
         const char* e = getenv("FSQ_DEBUG_FORCE_SLOW");
@@ -865,8 +914,14 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
             hipLaunchKernelGGL(kA_jacobian<false>, dim3((unsigned)(gA < 128 ? gA : 128)), dim3(64), 0, s, c, QA[cur], cA[cur], QB[cur], cB[cur], slow, cS[cur]);
         }
         if (gB > 0) {
-            if (ref) hipLaunchKernelGGL(kB_step<true>, dim3((unsigned)gB), dim3(64), 0, s, c, QB[cur], cB[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt]);
-            else hipLaunchKernelGGL(kB_step<false>, dim3((unsigned)gB), dim3(64), 0, s, c, QB[cur], cB[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt]);
+            // first pass over queue B, then the fits it parked in queue C (blocks beyond the C count leave at once)
+            if (ref) {
+                hipLaunchKernelGGL((kB_step<true, false>), dim3((unsigned)gB), dim3(64), 0, s, c, QB[cur], cB[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur]);
+                hipLaunchKernelGGL((kB_step<true, true>), dim3((unsigned)gB), dim3(64), 0, s, c, QC, cC[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur]);
+            } else {
+                hipLaunchKernelGGL((kB_step<false, false>), dim3((unsigned)gB), dim3(64), 0, s, c, QB[cur], cB[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur]);
+                hipLaunchKernelGGL((kB_step<false, true>), dim3((unsigned)gB), dim3(64), 0, s, c, QC, cC[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur]);
+            }
         }
         boundB = boundA + boundB;                            // every candidate of this round ends in A[nxt], B[nxt] or is done
         boundA = boundB;

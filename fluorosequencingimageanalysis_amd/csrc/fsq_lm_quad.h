@@ -466,12 +466,15 @@ FSQ_DEV void quadlm_qrsolv(QuadLm& q, double* scr, unsigned ipvt, double sqrt_pa
 }
 
 // returns par; the step (by parameter index) is left in q.xp; scr = 14 doubles of LDS scratch, STRIDE apart
+// lmpar (mpfit.py:1970-2103) in two parts so that a caller can stop after a few Newton iterations on par and
+// resume later: everything that crosses an iteration is in QuadLmparSt (plus q.r upper/diagonal and q.sdiag).
+struct QuadLmparSt { double par, parl, paru, fp; int iter; bool done; };
+
 template <bool ALIASED, int STRIDE>
-FSQ_DEV double quadlm_lmpar(QuadLm& q, double* scr, unsigned ipvt, double delta, double par)
+FSQ_DEV void quadlm_lmpar_begin(QuadLm& q, double* scr, unsigned ipvt, double delta, double par, QuadLmparSt& st)
 {
     const int n = FSQ_NP;
-    double* scr2 = scr + 7 * STRIDE;
-    double wa1[FSQ_NP], wa2[FSQ_NP];
+    double wa1[FSQ_NP];
     int nsing = n;
     double dmax = __builtin_fabs(q.r[0][0]);
 #pragma unroll
@@ -496,7 +499,8 @@ FSQ_DEV double quadlm_lmpar(QuadLm& q, double* scr, unsigned ipvt, double delta,
     for (int m = 0; m < n; m++) { double t = q.dg[m] * q.xp[m]; dxnorm = fsq_fma(t, t, dxnorm); }
     dxnorm = fsq_sqrt(dxnorm);
     double fp = dxnorm - delta;
-    if (fp <= 0.1 * delta) return 0.;
+    st.iter = 0;
+    if (fp <= 0.1 * delta) { st.par = 0.; st.parl = 0.; st.paru = 0.; st.fp = fp; st.done = true; return; }
     double parl = 0.;
     if (nsing >= n) {
 #pragma unroll
@@ -533,7 +537,22 @@ FSQ_DEV double quadlm_lmpar(QuadLm& q, double* scr, unsigned ipvt, double delta,
     par = np_max2(par, parl);
     par = np_min2(par, paru);
     if (par == 0) par = gnorm / dxnorm;
-    for (int iter = 1;; iter++) {
+    st.par = par; st.parl = parl; st.paru = paru; st.fp = fp; st.done = false;
+}
+
+// runs Newton iterations until the reference's loop would break or `iter_limit` iterations (counted from the
+// start of lmpar) have been done; st.done tells which
+template <bool ALIASED, int STRIDE>
+FSQ_DEV void quadlm_lmpar_run(QuadLm& q, double* scr, unsigned ipvt, double delta, QuadLmparSt& st, int iter_limit)
+{
+    const int n = FSQ_NP;
+    double* scr2 = scr + 7 * STRIDE;
+    double wa1[FSQ_NP], wa2[FSQ_NP];
+    double par = st.par, parl = st.parl, paru = st.paru, fp = st.fp, dxnorm;
+    int iter = st.iter;
+    bool done = st.done;
+    while (!done && iter < iter_limit) {
+        iter++;
         if (par == 0) par = np_max2(FSQ_DWARF, paru * 0.001);
         double temp = fsq_sqrt(par);
         quadlm_qrsolv<ALIASED, STRIDE>(q, scr, ipvt, temp);
@@ -545,7 +564,7 @@ FSQ_DEV double quadlm_lmpar(QuadLm& q, double* scr, unsigned ipvt, double delta,
         dxnorm = fsq_sqrt(dxnorm);
         temp = fp;
         fp = dxnorm - delta;
-        if ((__builtin_fabs(fp) <= 0.1 * delta) || ((parl == 0) && (fp <= temp) && (temp < 0)) || (iter == 10)) break;
+        if ((__builtin_fabs(fp) <= 0.1 * delta) || ((parl == 0) && (fp <= temp) && (temp < 0)) || (iter == 10)) { done = true; break; }
         // wa1 = diag[ipvt] * wa2[ipvt] / dxnorm : gather wa2 by logical position through the scratch
 #pragma unroll
         for (int m = 0; m < n; m++) scr2[m * STRIDE] = wa2[m];
@@ -568,5 +587,14 @@ FSQ_DEV double quadlm_lmpar(QuadLm& q, double* scr, unsigned ipvt, double delta,
         if (fp < 0) paru = np_min2(paru, par);
         par = np_max2(parl, par + parc);
     }
-    return par;
+    st.par = par; st.parl = parl; st.paru = paru; st.fp = fp; st.iter = iter; st.done = done;
+}
+
+template <bool ALIASED, int STRIDE>
+FSQ_DEV double quadlm_lmpar(QuadLm& q, double* scr, unsigned ipvt, double delta, double par)
+{
+    QuadLmparSt st;
+    quadlm_lmpar_begin<ALIASED, STRIDE>(q, scr, ipvt, delta, par, st);
+    quadlm_lmpar_run<ALIASED, STRIDE>(q, scr, ipvt, delta, st, 10);
+    return st.par;
 }
