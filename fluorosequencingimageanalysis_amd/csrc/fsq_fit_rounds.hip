@@ -502,8 +502,11 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
 #ifndef FSQ_LMPAR_FIRST
 #define FSQ_LMPAR_FIRST 3
 #endif
+#ifndef FSQ_KB_WAVES
+#define FSQ_KB_WAVES 2
+#endif
 template <bool ALIASED, bool RESUME>
-__global__ void __launch_bounds__(64, 1) kB_step(Ctx c, const double* __restrict__ QB, const int* __restrict__ cntB_p,
+__global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double* __restrict__ QB, const int* __restrict__ cntB_p,
                                                   double* __restrict__ QA_next, int* __restrict__ cntA_next,
                                                   double* __restrict__ QB_next, int* __restrict__ cntB_next,
                                                   double* __restrict__ QC, int* __restrict__ cntC)
@@ -537,8 +540,6 @@ __global__ void __launch_bounds__(64, 1) kB_step(Ctx c, const double* __restrict
         }
         const double llim1 = qb[A_LLIM1 * cap], gnorm = qb[B_GNORM * cap];
         double fnorm = qb[A_FNORM * cap], par = qb[A_PAR * cap], delta = qb[A_DELTA * cap], xnorm = qb[A_XNORM * cap], fnorm1;
-        double data[FSQ_NPIX];
-        roi_compact(c, idx, data);
 #pragma unroll
         for (int k = 0; k < FSQ_NP; k++) myscr[k * 64] = q.dg[k];
 #pragma unroll
@@ -646,7 +647,9 @@ __global__ void __launch_bounds__(64, 1) kB_step(Ctx c, const double* __restrict
         // trial evaluation (mpfit.py:1245)
         double wa4[FSQ_NPIX];
         {
-            double g[FSQ_NPIX];
+            double g[FSQ_NPIX], data[FSQ_NPIX];
+            asm volatile("" ::: "memory");          // the pixels are fetched here, not carried through lmpar
+            roi_compact(c, idx, data);
             fsq_model(wa2, g);
 #pragma unroll
             for (int i = 0; i < FSQ_NPIX; i++) wa4[i] = data[i] - g[i];
