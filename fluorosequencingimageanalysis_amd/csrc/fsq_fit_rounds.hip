@@ -160,6 +160,35 @@ __global__ void __launch_bounds__(256) kinit(Ctx c, double* __restrict__ QA)
     c.stat[i].vmax = mx; c.stat[i].vmean = vmean;
 }
 
+// kA's inputs for one quad, as they sit in registers between the loads and the LDS staging.  The loop of kA is
+// software-pipelined over them: the head (which fit) of the NEXT trip is requested at the top of a trip, the body
+// (that fit's pixels, residuals, x, diag) just before the hand-over stores of the trip, so both memory round trips
+// are hidden behind work instead of opening every trip.
+struct KaHead { int idx, niter, nfev; };
+struct KaBody { uint4 roi; double fv[7], x[2], dg[2], llim1; };
+FSQ_DEV KaHead ka_fetch_head(const double* qa, long long cap)
+{
+    KaHead h; int dummy;
+    unpack2(qa[A_IDX * cap], &h.idx, &dummy);
+    unpack2(qa[A_ITER * cap], &h.niter, &h.nfev);
+    return h;
+}
+FSQ_DEV KaBody ka_fetch_body(const Ctx& c, const double* qa, long long cap, int c4, int idx)
+{
+    KaBody b;
+    b.roi = *(const uint4*)(c.roi + (size_t)idx * 32 + c4 * 8);
+#pragma unroll
+    for (int m = 0; m < 7; m++) { const int k = c4 + 4 * m; b.fv[m] = (k < FSQ_NPIX) ? c.fvec[(size_t)idx * FSQ_NPIX + k] : 0.0; }
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        const int k = c4 + 4 * m;
+        b.x[m] = (k < FSQ_NP) ? qa[(A_X + k) * cap] : 0.0;
+        b.dg[m] = (k < FSQ_NP) ? qa[(A_DIAG + k) * cap] : 0.0;
+    }
+    b.llim1 = qa[A_LLIM1 * cap];
+    return b;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // kA: Jacobian round.  block = 64 threads = 16 quads, grid-stride over list A.
 // FAST = true: divisions by a shared divisor go through fsq_div_by (fsq_devmath.h) and every operand range that
@@ -177,12 +206,32 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
     if (!FAST && blockIdx.x == 0 && threadIdx.x == 0 && cntA > 0) atomicAdd(c.slow_total, cntA);
     double ca[FSQ_NPIX], cb[FSQ_NPIX], refl[FSQ_NPIX];
     RPH_DECL
-    for (int base = blockIdx.x * 16; base < cntA; base += gridDim.x * 16) {
+    const long long cap = c.cap;
+    const int stride = gridDim.x * 16;
+    // pipeline prologue: head and body of this wave's first trip
+    KaHead hd = {0, 1, 0};
+    KaBody bd = {};
+    int qpos = 0;
+    {
+        const int base0 = blockIdx.x * 16;
+        if (base0 + quad < cntA) {
+            qpos = FAST ? (base0 + quad) : slow[base0 + quad];
+            hd = ka_fetch_head(QA + qpos, cap);
+            bd = ka_fetch_body(c, QA + qpos, cap, c4, hd.idx);
+        }
+    }
+    for (int base = blockIdx.x * 16; base < cntA; base += stride) {
         RPH_MARK(0)
         const bool active = (base + quad) < cntA;
-        const long long cap = c.cap;
-        const int qpos = FAST ? (base + quad) : (active ? slow[base + quad] : 0);
         const double* qa = QA + qpos;
+        // head of the next trip: requested now, needed only at the end of this one
+        const bool activeN = (base + stride + quad) < cntA;
+        int qposN = 0;
+        KaHead hdN = {0, 1, 0};
+        if (activeN) {
+            qposN = FAST ? (base + stride + quad) : slow[base + stride + quad];
+            hdN = ka_fetch_head(QA + qposN, cap);
+        }
         bool hz = false, qhz = false;     // FAST: some operand left the range in which fsq_div_by == `/`
         int emin = 0;                     // FAST: smallest exponent among the tracked numerators
         int idx = 0;
@@ -193,12 +242,10 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
         int status = 0;
         double gnorm = 0.;
         if (active) {
-            int dummy;
-            unpack2(qa[A_IDX * cap], &idx, &dummy);
-            unpack2(qa[A_ITER * cap], &niter, &nfev);
+            idx = hd.idx; niter = hd.niter; nfev = hd.nfev;
             fresh = (nfev == 0);        // llim1 goes to LDS below; fnorm, par, delta, xnorm are fetched when first needed
             {   // lane c4 of the quad converts pixels 8*c4 .. 8*c4+7 of the compact ROI copy
-                const uint4 pw = *(const uint4*)(c.roi + (size_t)idx * 32 + c4 * 8);
+                const uint4 pw = bd.roi;
                 const unsigned w[4] = {pw.x, pw.y, pw.z, pw.w};
 #pragma unroll
                 for (int t = 0; t < 8; t++) {
@@ -206,9 +253,13 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                     if (k < FSQ_NPIX) QL(Q_DATA, k) = (double)((w[t >> 1] >> (16 * (t & 1))) & 0xffffu);
                 }
             }
-            if (!fresh) for (int k = c4; k < FSQ_NPIX; k += 4) QL(Q_FVEC, k) = c.fvec[(size_t)idx * FSQ_NPIX + k];
-            for (int k = c4; k < FSQ_NP; k += 4) { QL(Q_X, k) = qa[(A_X + k) * cap]; QL(Q_DIAG, k) = qa[(A_DIAG + k) * cap]; }
-            if (c4 == 0) QL(Q_TMP, 6) = qa[A_LLIM1 * cap];
+            if (!fresh) {
+#pragma unroll
+                for (int m = 0; m < 7; m++) { const int k = c4 + 4 * m; if (k < FSQ_NPIX) QL(Q_FVEC, k) = bd.fv[m]; }
+            }
+#pragma unroll
+            for (int m = 0; m < 2; m++) { const int k = c4 + 4 * m; if (k < FSQ_NP) { QL(Q_X, k) = bd.x[m]; QL(Q_DIAG, k) = bd.dg[m]; } }
+            if (c4 == 0) QL(Q_TMP, 6) = bd.llim1;
         }
         WAVE_SYNC();
         RPH_MARK(1)
@@ -457,6 +508,9 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                 c.out[idx] = o;
             }
         }
+        // body of the next trip: on its way while this trip's results are stored
+        KaBody bdN = {};
+        if (activeN) bdN = ka_fetch_body(c, QA + qposN, cap, c4, hdN.idx);
         // ---- ... or hand it over to the step round: one queue-B slot per surviving quad -------------------------
         {
             bool go = active && (status == 0);
@@ -489,6 +543,7 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
             }
         }
         RPH_MARK(6)
+        hd = hdN; bd = bdN; qpos = qposN;
     }
     RPH_FLUSH(8)
 }
