@@ -564,7 +564,7 @@ template <bool ALIASED, bool RESUME>
 __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double* __restrict__ QB, const int* __restrict__ cntB_p,
                                                   double* __restrict__ QA_next, int* __restrict__ cntA_next,
                                                   double* __restrict__ QB_next, int* __restrict__ cntB_next,
-                                                  double* __restrict__ QC, int* __restrict__ cntC)
+                                                  double* __restrict__ QC, int* __restrict__ cntC, int lm_first)
 {
     __shared__ double scr[21 * 64];
     const int lane = threadIdx.x;
@@ -605,7 +605,7 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
             QuadLmparSt st;
             if (!RESUME) {
                 quadlm_lmpar_begin<ALIASED, 64>(q, myscr, ipvt, delta, par, st);
-                quadlm_lmpar_run<ALIASED, 64>(q, myscr, ipvt, delta, st, FSQ_LMPAR_FIRST);
+                quadlm_lmpar_run<ALIASED, 64>(q, myscr, ipvt, delta, st, lm_first);
             } else {
                 int it, dm;
                 unpack2(qb[C_LMIT * cap], &it, &dm);
@@ -973,17 +973,21 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
         }
         if (gB > 0) {
             // first pass over queue B, then the fits it parked in queue C (blocks beyond the C count leave at once)
+            // With few fits left a round is pure launch + wave latency: lmpar then runs to the end in the first pass
+            // (nothing is parked) and the resume launch is skipped.
+            const bool two_pass = (boundA + boundB) > 32768;
+            const int lm_first = two_pass ? FSQ_LMPAR_FIRST : 10;
             if (ref) {
-                hipLaunchKernelGGL((kB_step<true, false>), dim3((unsigned)gB), dim3(64), 0, s, c, QB[cur], cB[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur]);
-                hipLaunchKernelGGL((kB_step<true, true>), dim3((unsigned)gB), dim3(64), 0, s, c, QC, cC[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur]);
+                hipLaunchKernelGGL((kB_step<true, false>), dim3((unsigned)gB), dim3(64), 0, s, c, QB[cur], cB[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur], lm_first);
+                if (two_pass) hipLaunchKernelGGL((kB_step<true, true>), dim3((unsigned)gB), dim3(64), 0, s, c, QC, cC[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur], 10);
             } else {
-                hipLaunchKernelGGL((kB_step<false, false>), dim3((unsigned)gB), dim3(64), 0, s, c, QB[cur], cB[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur]);
-                hipLaunchKernelGGL((kB_step<false, true>), dim3((unsigned)gB), dim3(64), 0, s, c, QC, cC[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur]);
+                hipLaunchKernelGGL((kB_step<false, false>), dim3((unsigned)gB), dim3(64), 0, s, c, QB[cur], cB[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur], lm_first);
+                if (two_pass) hipLaunchKernelGGL((kB_step<false, true>), dim3((unsigned)gB), dim3(64), 0, s, c, QC, cC[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur], 10);
             }
         }
         boundB = boundA + boundB;                            // every candidate of this round ends in A[nxt], B[nxt] or is done
         boundA = boundB;
-        if ((round & 3) == 3 || boundB <= 65536) {
+        if ((round & 3) == 3) {                              // (rounds on empty queues cost a few empty launches)
             FSQ_HIP_CHECK(hipMemcpyAsync(h_cnt, ctl, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
             FSQ_HIP_CHECK(hipStreamSynchronize(s));
             boundA = h_cnt[4 * nxt];
