@@ -957,15 +957,31 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
     FSQ_HIP_CHECK(hipMemcpyAsync(ctl, h_init, sizeof(h_init), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(kinit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c, QA[0]);
     const bool ref = (mode == FSQ_MODE_REF);
-    const long long full = (long long)cus * 8;
+    // Grid sizing: one block per loop trip (16 fits in kA, 64 in kB), so blocks retire continuously.  The hardware
+    // dispatcher then balances the very uneven trip times, and the small late-round kernels of ANOTHER stream
+    // (engine.LanePipeline) find free CU slots between them.  FSQ_TRIPS_PER_BLOCK=t gives every block t trips;
+    // t = 0 launches resident grids (8 waves per CU) that stride over the queue - measured 7% slower.
+    long long full = (long long)cus * 8;
+    int trips = 1;
+    {
+        const char* e = getenv("FSQ_TRIPS_PER_BLOCK");
+        if (e) trips = atoi(e);
+    }
     int h_cnt[12];
-    long long boundA = n, boundB = 0;                        // host-side upper bounds of the queue sizes
+    long long boundA = n, boundB = 0, alive = n;             // host-side upper bounds of the queue sizes
     for (int round = 0;; round++) {
         const int cur = round & 1, nxt = cur ^ 1;
         FSQ_HIP_CHECK(hipMemsetAsync(cA[nxt], 0, 4 * sizeof(int), s));      // A, B and slow counters of the next set
-        long long gA = (boundA + 15) / 16, gB = (boundA + boundB + 63) / 64;
-        if (gA > full) gA = full;
-        if (gB > full) gB = full;
+        long long nB = boundA + boundB;
+        if (nB > alive) nB = alive;
+        long long gA = (boundA + 15) / 16, gB = (nB + 63) / 64;
+        if (trips > 0) {
+            gA = (gA + trips - 1) / trips;
+            gB = (gB + trips - 1) / trips;
+        } else {
+            if (gA > full) gA = full;
+            if (gB > full) gB = full;
+        }
         if (gA > 0) {
             hipLaunchKernelGGL(kA_jacobian<true>, dim3((unsigned)gA), dim3(64), 0, s, c, QA[cur], cA[cur], QB[cur], cB[cur], slow, cS[cur]);
             // the plain-division build drains the (normally empty) slow list: its blocks leave at once when it is
@@ -975,7 +991,7 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
             // first pass over queue B, then the fits it parked in queue C (blocks beyond the C count leave at once)
             // With few fits left a round is pure launch + wave latency: lmpar then runs to the end in the first pass
             // (nothing is parked) and the resume launch is skipped.
-            const bool two_pass = (boundA + boundB) > 32768;
+            const bool two_pass = nB > 32768;
             const int lm_first = two_pass ? FSQ_LMPAR_FIRST : 10;
             if (ref) {
                 hipLaunchKernelGGL((kB_step<true, false>), dim3((unsigned)gB), dim3(64), 0, s, c, QB[cur], cB[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur], lm_first);
@@ -985,13 +1001,14 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
                 if (two_pass) hipLaunchKernelGGL((kB_step<false, true>), dim3((unsigned)gB), dim3(64), 0, s, c, QC, cC[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur], 10);
             }
         }
-        boundB = boundA + boundB;                            // every candidate of this round ends in A[nxt], B[nxt] or is done
+        boundB = nB;                                         // every candidate of this round ends in A[nxt], B[nxt] or is done
         boundA = boundB;
         if ((round & 3) == 3) {                              // (rounds on empty queues cost a few empty launches)
             FSQ_HIP_CHECK(hipMemcpyAsync(h_cnt, ctl, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
             FSQ_HIP_CHECK(hipStreamSynchronize(s));
             boundA = h_cnt[4 * nxt];
             boundB = h_cnt[4 * nxt + 1];
+            alive = boundA + boundB;
             g_last_slow = h_cnt[8];
             if (boundA == 0 && boundB == 0) break;
         }

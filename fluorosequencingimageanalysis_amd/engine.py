@@ -167,6 +167,49 @@ class Engine:
         return self.cand[:total].cpu().numpy(), self.counts.cpu().numpy(), self.offsets.cpu().numpy()
 
 
+class LanePipeline:
+    """Several Engines ("lanes"), each on its own HIP stream and host thread, working through successive batches.
+
+    The LM fit of one batch ends in a long tail of rounds with few fits left (a fit may need 200 sequential
+    iterations; those rounds are launch/latency bound and leave most CUs idle).  Fits of different batches are
+    independent, so a second lane whose batch is offset in time fills those idle CUs with the busy early rounds of
+    its own batch - the multi-batch analogue of the reference's multiprocessing.Pool over image partitions
+    (pflib.py:1046-1111).  Results are unaffected: every lane runs the same kernels on its own buffers."""
+
+    def __init__(self, engines):
+        self.engines = list(engines)
+        torch = self.engines[0].torch
+        self.streams = [torch.cuda.Stream(device=e.dev) for e in self.engines]
+
+    def run(self, work, n_steps, stagger_s=0.0):
+        """Call work(lane, step, engine) for step in range(n_steps) in every lane (lane k starts k*stagger_s late).
+        Returns when all lanes are done and their streams are idle; re-raises the first lane error."""
+        import threading
+        import time
+        torch = self.engines[0].torch
+        errs = []
+
+        def body(k):
+            try:
+                torch.cuda.set_device(self.engines[k].dev)
+                with torch.cuda.stream(self.streams[k]):
+                    if k and stagger_s > 0:
+                        time.sleep(k * stagger_s)
+                    for i in range(n_steps):
+                        work(k, i, self.engines[k])
+                    self.streams[k].synchronize()
+            except BaseException as e:      # noqa: BLE001 - handed to the caller below
+                errs.append(e)
+
+        ths = [threading.Thread(target=body, args=(k,), daemon=True) for k in range(len(self.engines))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errs:
+            raise errs[0]
+
+
 def fit_rois(rois, mode=N.MODE_REF):
     """LM-fit stand-alone 5x5 ROIs (uint16[n,5,5]); returns the FsqRow table on the host."""
     torch = _torch()
