@@ -194,6 +194,12 @@ FSQ_DEV KaBody ka_fetch_body(const Ctx& c, const double* qa, long long cap, int 
 // FAST = true: divisions by a shared divisor go through fsq_div_by (fsq_devmath.h) and every operand range that
 // makes it bit-identical to `/` is checked on the way; a quad that leaves those ranges writes nothing and appends
 // its queue position to `slow`, which the FAST = false build (plain divisions, same code) works off next.
+// With one trip per block (the default grid) there is no next trip to prefetch for; FSQ_KA_PIPELINE=1 compiles the
+// software pipeline back in for resident grids (FSQ_TRIPS_PER_BLOCK=0).
+#ifndef FSQ_KA_PIPELINE
+#define FSQ_KA_PIPELINE 0
+#endif
+static constexpr bool KA_PIPELINE = FSQ_KA_PIPELINE != 0;
 template <bool FAST>
 __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __restrict__ QA, const int* __restrict__ cntA_p,
                                                      double* __restrict__ QB, int* __restrict__ cntB_p,
@@ -225,7 +231,7 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
         const bool active = (base + quad) < cntA;
         const double* qa = QA + qpos;
         // head of the next trip: requested now, needed only at the end of this one
-        const bool activeN = (base + stride + quad) < cntA;
+        const bool activeN = KA_PIPELINE && (base + stride + quad) < cntA;
         int qposN = 0;
         KaHead hdN = {0, 1, 0};
         if (activeN) {
@@ -962,10 +968,14 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
     // (engine.LanePipeline) find free CU slots between them.  FSQ_TRIPS_PER_BLOCK=t gives every block t trips;
     // t = 0 launches resident grids (8 waves per CU) that stride over the queue - measured 7% slower.
     long long full = (long long)cus * 8;
-    int trips = 1;
+    int trips = 1, lm_first_cfg = FSQ_LMPAR_FIRST, sync_mask = 3;
+    long long two_pass_min = 131072;
     {
         const char* e = getenv("FSQ_TRIPS_PER_BLOCK");
         if (e) trips = atoi(e);
+        if ((e = getenv("FSQ_LMPAR_FIRST_ITERS")) != nullptr && atoi(e) >= 1 && atoi(e) <= 10) lm_first_cfg = atoi(e);
+        if ((e = getenv("FSQ_TWO_PASS_MIN")) != nullptr) two_pass_min = atoll(e);
+        if ((e = getenv("FSQ_SYNC_EVERY")) != nullptr && atoi(e) >= 1) sync_mask = atoi(e) - 1;     // power of two
     }
     int h_cnt[12];
     long long boundA = n, boundB = 0, alive = n;             // host-side upper bounds of the queue sizes
@@ -991,8 +1001,8 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
             // first pass over queue B, then the fits it parked in queue C (blocks beyond the C count leave at once)
             // With few fits left a round is pure launch + wave latency: lmpar then runs to the end in the first pass
             // (nothing is parked) and the resume launch is skipped.
-            const bool two_pass = nB > 32768;
-            const int lm_first = two_pass ? FSQ_LMPAR_FIRST : 10;
+            const bool two_pass = nB > two_pass_min && lm_first_cfg < 10;
+            const int lm_first = two_pass ? lm_first_cfg : 10;
             if (ref) {
                 hipLaunchKernelGGL((kB_step<true, false>), dim3((unsigned)gB), dim3(64), 0, s, c, QB[cur], cB[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur], lm_first);
                 if (two_pass) hipLaunchKernelGGL((kB_step<true, true>), dim3((unsigned)gB), dim3(64), 0, s, c, QC, cC[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur], 10);
@@ -1003,7 +1013,7 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
         }
         boundB = nB;                                         // every candidate of this round ends in A[nxt], B[nxt] or is done
         boundA = boundB;
-        if ((round & 3) == 3) {                              // (rounds on empty queues cost a few empty launches)
+        if ((round & sync_mask) == sync_mask) {                              // (rounds on empty queues cost a few empty launches)
             FSQ_HIP_CHECK(hipMemcpyAsync(h_cnt, ctl, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
             FSQ_HIP_CHECK(hipStreamSynchronize(s));
             boundA = h_cnt[4 * nxt];
