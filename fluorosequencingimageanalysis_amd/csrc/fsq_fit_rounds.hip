@@ -193,7 +193,9 @@ FSQ_DEV KaBody ka_fetch_body(const Ctx& c, const double* qa, long long cap, int 
 // kA: Jacobian round.  block = 64 threads = 16 quads, grid-stride over list A.
 // FAST = true: divisions by a shared divisor go through fsq_div_by (fsq_devmath.h) and every operand range that
 // makes it bit-identical to `/` is checked on the way; a quad that leaves those ranges writes nothing and appends
-// its queue position to `slow`, which the FAST = false build (plain divisions, same code) works off next.
+// a copy of its queue-A record to the slow queue SQ, which the FAST = false build (plain divisions, same code) works
+// off when the host next looks (fits are independent, so a fit may fall a few rounds behind).
+// The FAST build also zeroes the queue counters of the next round (nobody reads or appends to them during kA).
 // With one trip per block (the default grid) there is no next trip to prefetch for; FSQ_KA_PIPELINE=1 compiles the
 // software pipeline back in for resident grids (FSQ_TRIPS_PER_BLOCK=0).
 #ifndef FSQ_KA_PIPELINE
@@ -203,13 +205,15 @@ static constexpr bool KA_PIPELINE = FSQ_KA_PIPELINE != 0;
 template <bool FAST>
 __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __restrict__ QA, const int* __restrict__ cntA_p,
                                                      double* __restrict__ QB, int* __restrict__ cntB_p,
-                                                     int* __restrict__ slow, int* __restrict__ slow_cnt)
+                                                     double* __restrict__ SQ, int* __restrict__ slow_cnt,
+                                                     int* __restrict__ next_counters)
 {
     __shared__ double lds[Q_KA_END * 16];
     const int lane = threadIdx.x, quad = lane >> 2, c4 = lane & 3, qbase = lane & ~3;
     const int n7 = FSQ_NP;
     const int cntA = FAST ? *cntA_p : *slow_cnt;
     if (!FAST && blockIdx.x == 0 && threadIdx.x == 0 && cntA > 0) atomicAdd(c.slow_total, cntA);
+    if (FAST && blockIdx.x == 0 && threadIdx.x < 4) next_counters[threadIdx.x] = 0;
     double ca[FSQ_NPIX], cb[FSQ_NPIX], refl[FSQ_NPIX];
     RPH_DECL
     const long long cap = c.cap;
@@ -218,10 +222,10 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
     KaHead hd = {0, 1, 0};
     KaBody bd = {};
     int qpos = 0;
-    {
+    if (KA_PIPELINE) {
         const int base0 = blockIdx.x * 16;
         if (base0 + quad < cntA) {
-            qpos = FAST ? (base0 + quad) : slow[base0 + quad];
+            qpos = base0 + quad;
             hd = ka_fetch_head(QA + qpos, cap);
             bd = ka_fetch_body(c, QA + qpos, cap, c4, hd.idx);
         }
@@ -229,13 +233,18 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
     for (int base = blockIdx.x * 16; base < cntA; base += stride) {
         RPH_MARK(0)
         const bool active = (base + quad) < cntA;
+        if (!KA_PIPELINE && active) {           // plain loads at the top of the trip
+            qpos = base + quad;
+            hd = ka_fetch_head(QA + qpos, cap);
+            bd = ka_fetch_body(c, QA + qpos, cap, c4, hd.idx);
+        }
         const double* qa = QA + qpos;
         // head of the next trip: requested now, needed only at the end of this one
         const bool activeN = KA_PIPELINE && (base + stride + quad) < cntA;
         int qposN = 0;
         KaHead hdN = {0, 1, 0};
         if (activeN) {
-            qposN = FAST ? (base + stride + quad) : slow[base + stride + quad];
+            qposN = base + stride + quad;
             hdN = ka_fetch_head(QA + qposN, cap);
         }
         bool hz = false, qhz = false;     // FAST: some operand left the range in which fsq_div_by == `/`
@@ -522,7 +531,8 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
             bool go = active && (status == 0);
             if (FAST) {
                 int sat = wave_reserve(slow_cnt, qhz && c4 == 0);
-                if (qhz && c4 == 0) slow[sat] = base + quad;
+                sat = __shfl(sat, qbase);
+                if (qhz) for (int f = c4; f < A_LEN; f += 4) SQ[(size_t)sat + f * cap] = qa[f * cap];
                 go = go && !qhz;
             }
             int at = wave_reserve(cntB_p, go && c4 == 0);
@@ -549,6 +559,7 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
             }
         }
         RPH_MARK(6)
+        if (!KA_PIPELINE) break;                // one trip per block: the host launches a block per 16 queue entries
         hd = hdN; bd = bdN; qpos = qposN;
     }
     RPH_FLUSH(8)
@@ -921,7 +932,7 @@ extern "C" int64_t fsq_fit_workspace_bytes(int64_t n)
     const size_t cap = (size_t)n + 64;
     size_t b = 4096;
     b += al256(cap * 64) + al256(cap * FSQ_NPIX * 8) + al256(cap * sizeof(FitOut)) + al256(cap * sizeof(FitStat));
-    b += 2 * al256(cap * A_LEN * 8) + 2 * al256(cap * B_LEN * 8) + al256(cap * C_LEN * 8) + al256(cap * sizeof(int));
+    b += 2 * al256(cap * A_LEN * 8) + 2 * al256(cap * B_LEN * 8) + al256(cap * C_LEN * 8) + al256(cap * A_LEN * 8);
     return (int64_t)b;
 }
 
@@ -933,7 +944,7 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
     if (n > 2000000000ll) return FSQ_ENOTIMPL;
     const size_t cap = (size_t)n + 64;
     unsigned char* ws = (unsigned char*)d_ws;
-    int* ctl = (int*)ws;                                     // per ping/pong set: {queue A, queue B, slow list, pad}
+    int* ctl = (int*)ws;            // per ping/pong set: {queue A, queue B, -, queue C}; [8] slow total, [9] slow queue
     size_t o = 4096;
     Ctx c;
     c.src = d_src; c.cand = d_cand; c.H = H; c.W = W; c.n = n; c.from_image = from_image ? 1 : 0; c.cap = (long long)cap;
@@ -951,7 +962,8 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
     int* cS[2] = {ctl + 2, ctl + 6};
     int* cC[2] = {ctl + 3, ctl + 7};
     double* QC = (double*)(ws + o); o += al256(cap * C_LEN * 8);
-    int* slow = (int*)(ws + o); o += al256(cap * sizeof(int));
+    double* SQ = (double*)(ws + o); o += al256(cap * A_LEN * 8);
+    int* cSlow = ctl + 9;
     {
         const char* e = getenv("FSQ_DEBUG_FORCE_SLOW");
         c.force_slow_mod = e ? atoi(e) : 0;
@@ -969,7 +981,7 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
     // t = 0 launches resident grids (8 waves per CU) that stride over the queue - measured 7% slower.
     long long full = (long long)cus * 8;
     int trips = 1, lm_first_cfg = FSQ_LMPAR_FIRST, sync_mask = 3;
-    long long two_pass_min = 131072;
+    long long two_pass_min = 524288;
     {
         const char* e = getenv("FSQ_TRIPS_PER_BLOCK");
         if (e) trips = atoi(e);
@@ -979,24 +991,33 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
     }
     int h_cnt[12];
     long long boundA = n, boundB = 0, alive = n;             // host-side upper bounds of the queue sizes
+    long long slow_pending = 0;                              // slow-queue length at the last look
     for (int round = 0;; round++) {
         const int cur = round & 1, nxt = cur ^ 1;
-        FSQ_HIP_CHECK(hipMemsetAsync(cA[nxt], 0, 4 * sizeof(int), s));      // A, B and slow counters of the next set
         long long nB = boundA + boundB;
         if (nB > alive) nB = alive;
-        long long gA = (boundA + 15) / 16, gB = (nB + 63) / 64;
-        if (trips > 0) {
-            gA = (gA + trips - 1) / trips;
-            gB = (gB + trips - 1) / trips;
-        } else {
-            if (gA > full) gA = full;
-            if (gB > full) gB = full;
+        long long gA = (boundA + 15) / 16;          // kA: a block per trip unless built with FSQ_KA_PIPELINE
+        if (KA_PIPELINE) {
+            if (trips > 0) gA = (gA + trips - 1) / trips;
+            else if (gA > full) gA = full;
         }
-        if (gA > 0) {
-            hipLaunchKernelGGL(kA_jacobian<true>, dim3((unsigned)gA), dim3(64), 0, s, c, QA[cur], cA[cur], QB[cur], cB[cur], slow, cS[cur]);
-            // the plain-division build drains the (normally empty) slow list: its blocks leave at once when it is
-            hipLaunchKernelGGL(kA_jacobian<false>, dim3((unsigned)(gA < 128 ? gA : 128)), dim3(64), 0, s, c, QA[cur], cA[cur], QB[cur], cB[cur], slow, cS[cur]);
+        if (gA > 0)         // (also zeroes the counters of set nxt)
+            hipLaunchKernelGGL(kA_jacobian<true>, dim3((unsigned)gA), dim3(64), 0, s, c, QA[cur], cA[cur], QB[cur], cB[cur], SQ, cSlow, cA[nxt]);
+        else
+            FSQ_HIP_CHECK(hipMemsetAsync(cA[nxt], 0, 4 * sizeof(int), s));
+        if (slow_pending > 0) {
+            // fits that left the guarded operand ranges since the host last looked: the plain-division build takes them
+            // from the slow queue and appends their queue-B records to this round's
+            long long gS = (alive + 15) / 16;       // the slow queue may have grown since the host looked: size for all
+            hipLaunchKernelGGL(kA_jacobian<false>, dim3((unsigned)gS), dim3(64), 0, s, c, SQ, cSlow, QB[cur], cB[cur], SQ, cSlow, cA[nxt]);
+            FSQ_HIP_CHECK(hipMemsetAsync(cSlow, 0, sizeof(int), s));
+            nB += slow_pending;
+            if (alive < nB) alive = nB;
+            slow_pending = 0;
         }
+        long long gB = (nB + 63) / 64;
+        if (trips > 0) gB = (gB + trips - 1) / trips;
+        else if (gB > full) gB = full;
         if (gB > 0) {
             // first pass over queue B, then the fits it parked in queue C (blocks beyond the C count leave at once)
             // With few fits left a round is pure launch + wave latency: lmpar then runs to the end in the first pass
@@ -1020,7 +1041,10 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
             boundB = h_cnt[4 * nxt + 1];
             alive = boundA + boundB;
             g_last_slow = h_cnt[8];
-            if (boundA == 0 && boundB == 0) break;
+            slow_pending = h_cnt[9];
+            alive += slow_pending;
+            if (getenv("FSQ_DEBUG_TRACE")) fprintf(stderr, "round %d: A=%lld B=%lld slow=%lld total_slow=%d\n", round, boundA, boundB, slow_pending, h_cnt[8]);
+            if (boundA == 0 && boundB == 0 && slow_pending == 0) break;
         }
         if (getenv("FSQ_DEBUG_MAX_ROUNDS") && round + 1 >= atoi(getenv("FSQ_DEBUG_MAX_ROUNDS"))) break;
         if (round > 100000) return FSQ_EHIP;                 // cannot happen: every pass shrinks delta or accepts
