@@ -574,6 +574,10 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
 #ifndef FSQ_LMPAR_FIRST
 #define FSQ_LMPAR_FIRST 3
 #endif
+#ifndef FSQ_KB_LOOP
+#define FSQ_KB_LOOP 0
+#endif
+static constexpr bool KB_LOOP = FSQ_KB_LOOP != 0;
 #ifndef FSQ_KB_WAVES
 #define FSQ_KB_WAVES 2
 #endif
@@ -827,6 +831,7 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
             }
         }
         RPH_MARK(6)
+        if (!KB_LOOP) break;                    // one trip per block (see fsq_launch_fit_rounds)
     }
     RPH_FLUSH(0)
 }
@@ -1015,9 +1020,11 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
             if (alive < nB) alive = nB;
             slow_pending = 0;
         }
-        long long gB = (nB + 63) / 64;
-        if (trips > 0) gB = (gB + trips - 1) / trips;
-        else if (gB > full) gB = full;
+        long long gB = (nB + 63) / 64;              // kB: a block per trip unless built with FSQ_KB_LOOP
+        if (KB_LOOP) {
+            if (trips > 0) gB = (gB + trips - 1) / trips;
+            else if (gB > full) gB = full;
+        }
         if (gB > 0) {
             // first pass over queue B, then the fits it parked in queue C (blocks beyond the C count leave at once)
             // With few fits left a round is pure launch + wave latency: lmpar then runs to the end in the first pass
