@@ -196,7 +196,11 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("fit_kernel_hbm_bytes_per_launch")
+            # measured for one pass over the 1 024-field batch (rocprofv3 --pmc, tools/collect_profiles.sh); a launch
+            # covers one lane's share of it
+            traffic = json.load(open(tpath)).get("fit_kernel_hbm_bytes_per_1024_field_pass")
+            if traffic is not None:
+                traffic = traffic * (a.fields / 1024.0) / lanes
         out = {
             "metric": "psf_lm_fits_per_sec", "value": fits_per_s, "unit": "fits/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
