@@ -321,13 +321,19 @@ __global__ void __launch_bounds__(256) k2_scan_field(int* __restrict__ tile_coun
 }
 
 // pass 3. single block: exclusive scan of the field totals -> offsets[0..n_fields], counts[n_fields] = total
-__global__ void __launch_bounds__(256) k2_scan_all(int* __restrict__ counts, int* __restrict__ offsets, int n_fields)
+// Also the exactness check of the threshold: numpy.mean sums the int64 response in float64, which equals the exact
+// integer sum used here as long as that sum stays below 2^53 (all terms are >= 0, so every partial sum does too).
+// A field beyond that makes the total -1, which the caller reports as "not implemented" instead of a wrong answer.
+__global__ void __launch_bounds__(256) k2_scan_all(int* __restrict__ counts, int* __restrict__ offsets, int n_fields,
+                                                   const unsigned long long* __restrict__ field_sum)
 {
     const int tid = threadIdx.x;
     __shared__ int part[256];
-    __shared__ int carry;
-    if (tid == 0) carry = 0;
+    __shared__ int carry, inexact;
+    if (tid == 0) { carry = 0; inexact = 0; }
     __syncthreads();
+    for (int i = tid; i < n_fields; i += 256)
+        if (field_sum[i] >= (1ull << 53)) inexact = 1;
     for (int base = 0; base < n_fields; base += 256) {
         int i = base + tid;
         int v = (i < n_fields) ? counts[i] : 0;
@@ -344,7 +350,7 @@ __global__ void __launch_bounds__(256) k2_scan_all(int* __restrict__ counts, int
         if (tid == 255) carry += part[255];
         __syncthreads();
     }
-    if (tid == 0) { offsets[n_fields] = carry; counts[n_fields] = carry; }
+    if (tid == 0) { offsets[n_fields] = carry; counts[n_fields] = inexact ? -1 : carry; }
 }
 
 // pass 4. same grid as pass 1: ordered write of (field, h, w)
@@ -422,11 +428,12 @@ extern "C" int fsq_detect(const uint16_t* d_img, int n_fields, int H, int W, con
         if (prm->K[i] > 2147483647ll || prm->K[i] < -2147483648ll) return FSQ_ENOTIMPL;
         dc.K[i] = (int)prm->K[i];
     }
-    // exactness domain of numpy.mean on the int64 response: the running float64 sum must stay < 2^53
+    // exactness domain: the integer sum of the response must not wrap (its float64 exactness, < 2^53, is checked
+    // on the actual data by k2_scan_all)
     {
         long double kmax = 0;
         for (int i = 0; i < ksz * ksz; i++) if (dc.K[i] > 0) kmax += dc.K[i];
-        if (kmax * 65535.0L * (long double)H * W >= 9007199254740992.0L) return FSQ_ENOTIMPL;
+        if (kmax * 65535.0L * (long double)H * W >= 18446744073709551615.0L) return FSQ_ENOTIMPL;
     }
     hipStream_t s = (hipStream_t)stream;
     unsigned char* ws = (unsigned char*)d_workspace;
@@ -452,7 +459,7 @@ extern "C" int fsq_detect(const uint16_t* d_img, int n_fields, int H, int W, con
                        prm->c_std, n_fields, thr);
     hipLaunchKernelGGL(k2_count, dim3(tiles, n_fields), dim3(256), 0, s, cm, H, W, thr, tiles, tile_count);
     hipLaunchKernelGGL(k2_scan_field, dim3(n_fields), dim3(256), 0, s, tile_count, tiles, d_counts);
-    hipLaunchKernelGGL(k2_scan_all, dim3(1), dim3(256), 0, s, d_counts, d_offsets, n_fields);
+    hipLaunchKernelGGL(k2_scan_all, dim3(1), dim3(256), 0, s, d_counts, d_offsets, n_fields, field_sum);
     hipLaunchKernelGGL(k2_write, dim3(tiles, n_fields), dim3(256), 0, s, cm, H, W, thr, tiles, tile_count, d_offsets,
                        d_cand, (long long)cap);
     FSQ_HIP_CHECK(hipGetLastError());

@@ -101,6 +101,9 @@ class Engine:
                                self.ws.data_ptr(), self.ws.numel(), self._stream())
         N.check(rc, "fsq_detect")
         total = int(self.counts[self.n_fields].item())
+        if total < 0:
+            raise NotImplementedError("fsq_detect: the response of a field sums to 2^53 or more, beyond which "
+                                      "numpy.mean (pflib.py:250) is no longer the exact integer mean")
         if total > self.cap:                       # candidate buffer too small: grow and redo the pass
             self._alloc_cand(int(total * 1.25) + 1024)
             return self.detect(d_img, prm)

@@ -41,3 +41,26 @@ def phase_correlate(ref_image, reg_image, upsample_factor=1):
     if upsample_factor == 1:        # the reference returns integer pixel shifts in this branch (:75-92)
         return np.int64(r[0]), np.int64(r[1]), np.float64(r[2]), np.float64(r[3])
     return np.float64(r[0]), np.float64(r[1]), np.float64(r[2]), np.float64(r[3])
+
+
+def offsets_from_frames(alignment_frames, upsample_factor=20):
+    """Frame-to-frame alignment of one field's cycle stack: the loop of SequenceExperiment.offsets_from_frames
+    (flexlibrary.py:1717-1741) - offsets[0] = (0, 0) and offsets[f + 1] = phase_correlate(frame f, frame f + 1)[:2],
+    each relative to the PREVIOUS frame - with all pairs registered in one batched GPU call.
+    `alignment_frames`: sequence of 2-D images (or objects with an `.image` attribute, like flexlibrary.Image)."""
+    imgs = [np.asarray(getattr(f, "image", f), dtype=np.float64) for f in alignment_frames]
+    offsets = [(0, 0) for _ in imgs]
+    if len(imgs) < 2:
+        return offsets
+    for im in imgs:
+        if im.ndim != 2:
+            raise ValueError("phase_correlate only supports 2D images.")
+        if im.shape != imgs[0].shape:
+            raise ValueError("phase_correlate requires images of the same shape.")
+    out = phase_correlate_batch(np.stack(imgs[:-1]), np.stack(imgs[1:]), upsample_factor)
+    for f in range(len(imgs) - 1):
+        d_h, d_w = out[f][0], out[f][1]
+        if upsample_factor == 1:             # the reference returns numpy ints on this branch (phase_correlate.py:85-92)
+            d_h, d_w = np.int64(d_h), np.int64(d_w)
+        offsets[f + 1] = (d_h, d_w)
+    return offsets

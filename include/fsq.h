@@ -66,6 +66,8 @@ int64_t fsq_detect_workspace_bytes(int n_fields, int H, int W);
  *   d_img     uint16[n_fields][H][W]
  *   d_cand    int32[cap][3]  (field, h, w)            out
  *   d_counts  int32[n_fields + 1]                      out: per-field candidate counts, [n_fields] = total
+ *             (total = -1: the response image of some field sums to >= 2^53, where numpy.mean of the reference
+ *             stops being the exact integer mean this kernel computes - treat as "not implemented")
  *   d_offsets int32[n_fields + 1]                      out: exclusive prefix of d_counts (field f's
  *                                                           candidates are d_cand[offsets[f] .. +counts[f]))
  *   d_thr     double[n_fields] (may be NULL)           out: mean + c_std * std of the response image

@@ -1,0 +1,136 @@
+"""GPU tests (-m gpu) of BASELINE.json's other configurations and of the full-size batch:
+config 3 (cycle stack: registration + per-cycle fitting), config 5 (a 2 048x2 048 high-density field), config 2 at
+its full size through a size-independent property (1 024 copies of a golden field must each reproduce the reference's
+table for that field), and the two-lane pipeline bench.py uses."""
+import numpy as np
+import pytest
+
+from _util import bits_equal, load_field
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from fluorosequencingimageanalysis_amd import _native, engine, pflib, phase_correlate, synth
+    import oracle as O
+    O.build()
+    return torch, _native, engine, pflib, phase_correlate, synth, O
+
+
+def _same_table(got, rows, fits, keep, key):
+    """pflib-style dict `got` == the oracle's kept rows (keys in order, parameters and metrics bit for bit)."""
+    assert np.array_equal(np.array(list(got.keys()), dtype=np.int32).reshape(-1, 2), key)
+    r = rows[keep]
+    exp7 = np.stack([r[k] for k in ("h0", "w0", "H", "A", "sigma_h", "sigma_w", "theta")], axis=1)
+    got7 = np.array([[float(x) for x in v[:7]] for v in got.values()]).reshape(-1, 7)
+    assert bits_equal(got7, exp7).all()
+    expm = np.stack([r[k] for k in ("rmse", "r2", "s_n")], axis=1)
+    gotm = np.array([[float(v[9]), float(v[10]), float(v[11])] for v in got.values()]).reshape(-1, 3)
+    assert bits_equal(gotm, expm).all()
+
+
+def test_config3_cycle_stack_registration_and_fitting(env):
+    """4 channels x 8 cycles of one field (256x256 to keep the oracle quick): channel 0 registers the cycles exactly
+    like SequenceExperiment.offsets_from_frames (flexlibrary.py:1717-1741), every frame of every channel is fitted."""
+    torch, N, engine, pflib, pc, synth, O = env
+    n_cycles, shape = 8, (256, 256)
+    stacks = [synth.make_cycle_stack(30 + ch, n_cycles=n_cycles, shape=shape, n_spots=150) for ch in range(4)]
+    frames0, true_off = stacks[0]
+    offsets = pc.offsets_from_frames(list(frames0), upsample_factor=20)
+    assert offsets[0] == (0, 0) and len(offsets) == n_cycles
+    for f in range(n_cycles - 1):
+        exp = O.phase_correlate(frames0[f], frames0[f + 1], 20)               # CPU restatement (plain DFT)
+        assert float(offsets[f + 1][0]) == exp[0] and float(offsets[f + 1][1]) == exp[1]
+        step = true_off[f + 1] - true_off[f]                                  # content moved by +step => shift = -step
+        assert abs(offsets[f + 1][0] + step[0]) < 0.15 and abs(offsets[f + 1][1] + step[1]) < 0.15
+    # per-cycle fitting: all 32 frames in one batch; two of them checked in full against the oracle
+    allf = np.concatenate([st[0] for st in stacks])
+    out = pflib.find_peptides_batch(allf)
+    assert len(out) == 4 * n_cycles
+    for idx in (3, 4 * n_cycles - 1):
+        rows, fits, keep, key = O.find_peptides(allf[idx], n_threads=16)
+        _same_table(out[idx], rows, fits, keep, key)
+    # dropout: later cycles hold fewer spots
+    assert len(out[n_cycles - 1]) < len(out[0])
+
+
+def test_config5_large_dense_field(env):
+    """One 2 048x2 048 field with 5 000 spots (config 5's shape; the path stays reference-faithful fp64):
+    candidates and the consolidated table equal the oracle's."""
+    torch, N, engine, pflib, pc, synth, O = env
+    img = synth.make_field(77, (2048, 2048), 5000)
+    cand = pflib._psf_candidates(img)
+    exp = O.candidates(img)
+    assert len(cand) == len(exp) and np.array_equal(np.array(cand), exp)
+    got = pflib.find_peptides(img)
+    rows, fits, keep, key = O.find_peptides(img, n_threads=16)
+    _same_table(got, rows, fits, keep, key)
+
+
+def test_config2_full_size_replicated_golden(env):
+    """1 024 fields of 512x512 in one batch (4.3 M LM solves, the bench's size): every field is a copy of golden field
+    f1, so every field's candidate count and kept table must equal the reference's recorded output for f1."""
+    torch, N, E, pflib, pc, synth, O = env
+    g, img = load_field("f1_cfg2_512_500")
+    n = 1024
+    d_one = E.to_device_u16(img[None])
+    d_img = d_one.expand(n, -1, -1).contiguous()
+    eng = E.Engine(n, 512, 512)
+    prm = E.detect_params(5, pflib.default_correlation_matrix, 2)
+    total = eng.run(d_img, prm)
+    ncand = len(g["candidates"])
+    assert total == n * ncand
+    counts = eng.counts.cpu().numpy()
+    assert (counts[:n] == ncand).all() and counts[n] == total
+    assert N.lib().fsq_fit_last_slow_count() == 0
+    rows = eng.rows[:total].cpu().numpy().view(N.ROW_DTYPE).reshape(n, ncand)
+    p = np.stack([rows[k] for k in ("H", "A", "p2", "p3", "sigma_h", "sigma_w", "theta")], axis=-1)
+    assert bits_equal(p[0], g["params"]).all()                              # field 0 == the reference
+    assert (p.view(np.uint64) == p[0].view(np.uint64)[None]).all()          # every other field == field 0
+    assert (rows["status"] == g["status"][None]).all() and (rows["niter"] == g["niter"][None]).all()
+    nk = eng.nkeep.cpu().numpy()
+    assert (nk[:n] == nk[0]).all() and nk[0] == len(g["table_keys"])       # kept peaks == the reference's dict size
+    keep = eng.keep[:total].cpu().numpy().reshape(n, ncand)[:, :nk[0]]
+    assert (keep - (np.arange(n) * ncand)[:, None] == keep[0][None]).all()  # same kept candidates in the same order
+
+
+def test_lane_pipeline_equals_single_engine(env):
+    """engine.LanePipeline (two shares on their own streams / host threads, second one staggered) returns exactly what
+    one engine returns for the same fields."""
+    torch, N, E, pflib, pc, synth, O = env
+    imgs = np.stack([synth.make_field(500 + i, (256, 256), 120) for i in range(12)])
+    d_img = E.to_device_u16(imgs)
+    prm = E.detect_params(5, pflib.default_correlation_matrix, 2)
+    one = E.Engine(12, 256, 256)
+    total = one.run(d_img, prm)
+    ref_rows = one.rows[:total].cpu().numpy().tobytes()
+    ref_keep = one.keep[:total].cpu().numpy()
+    ref_nk = one.nkeep.cpu().numpy()
+    lanes = [E.Engine(6, 256, 256), E.Engine(6, 256, 256)]
+    pipe = E.LanePipeline(lanes)
+    totals = [[0, 0], [0, 0]]
+
+    def work(k, i, eng):
+        totals[k][i] = eng.run(d_img[6 * k:6 * k + 6], prm)
+
+    pipe.run(work, 2, stagger_s=0.01)
+    assert totals[0][0] + totals[1][0] == total and totals[0] == [totals[0][0]] * 2
+    got = b"".join(lanes[k].rows[:totals[k][1]].cpu().numpy().tobytes() for k in range(2))
+    # rows carry the field index inside their share: compare everything else
+    a = np.frombuffer(got, dtype=N.ROW_DTYPE).copy()
+    b = np.frombuffer(ref_rows, dtype=N.ROW_DTYPE).copy()
+    a["field"][totals[0][1]:] += 6
+    assert a.tobytes() == b.tobytes()
+    assert np.array_equal(np.concatenate([lanes[0].nkeep.cpu().numpy()[:6], lanes[1].nkeep.cpu().numpy()[:6]]), ref_nk[:12])
+    roff = one.offsets.cpu().numpy()
+    base = [0, totals[0][1]]
+    for k in range(2):
+        kk = lanes[k].keep[:totals[k][1]].cpu().numpy()
+        nk = lanes[k].nkeep.cpu().numpy()
+        off = lanes[k].offsets.cpu().numpy()
+        for f in range(6):      # only [offsets[f], offsets[f] + nkeep[f]) of a field's slice of `keep` is defined
+            g = 6 * k + f
+            assert np.array_equal(kk[off[f]:off[f] + nk[f]] + base[k], ref_keep[roff[g]:roff[g] + ref_nk[g]])
