@@ -78,6 +78,7 @@ def main():
     rank, world, local = D.init_from_env()
     assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
     assert torch.cuda.is_available(), "bench.py needs a GPU; the HIP path has no CPU fallback"
+    local = local % torch.cuda.device_count()      # (more ranks than GPUs only in the gloo rehearsal of the N > 1 path)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -133,6 +134,7 @@ def main():
                     pending[(kk, ii)] = (kept, done)
                 kept, done = pending.pop((k, i))
                 torch.cuda.current_stream().wait_event(done)
+                kept.record_stream(torch.cuda.current_stream())
                 D.gather_tables(kept, 0)
 
     def run_steps(n_steps, timed, stagger):
