@@ -214,13 +214,19 @@ def main():
                        "fields_per_gpu": a.fields, "candidates_per_gpu": int(total),
                        "parallelism": "fields sharded over %d rank(s), RCCL p2p gather of peak tables" % world},
             "fields_per_sec": a.fields * world * a.steps / dt,
-            "roofline": {"bound": "valu-fp64 (the LM solve is vector-ALU work: no MFMA-shaped contraction and ~40 GB/s of HBM, "
-                                  "so neither 'hbm' nor 'mfma' bounds it - see DESIGN.md)",
+            "roofline": {"bound": "valu-fp64",
+                         "note": "the LM solve is fp64 vector-ALU work with 98 B of algorithmic I/O per fit: there is no "
+                                 "MFMA-shaped contraction and it is not HBM-bound (see the hbm entry), so it is priced against "
+                                 "the fp64 VECTOR peak - DESIGN.md 4.2",
                          "kernel": "LM fit = kinit + rounds of (kA_jacobian, kB_step) + kfinish, timed as one unit",
                          "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
                          "launch_ms": fit_avg_ms, "fits_per_launch": int(total // lanes), "concurrent_launches": lanes,
-                         "launches": lanes * a.steps, "busy_ms": busy_ms, "flop_per_fit": FLOP_PER_FIT},
+                         "launches": lanes * a.steps, "busy_ms": busy_ms, "flop_per_fit": FLOP_PER_FIT,
+                         "hbm": {"algorithmic_bytes_per_fit": 98,
+                                 "algorithmic_GBps": 98.0 * total * a.steps / (busy_ms * 1e-3) / 1e9,
+                                 "traffic_GBps": (traffic * lanes * a.steps / (busy_ms * 1e-3) / 1e9) if traffic else None,
+                                 "peak_GBps": PEAK_HBM_GBS}},
         }
         if not a.no_cpu_baseline:
             cand, counts, offsets = engs[0].candidates(totals[0][0])

@@ -187,6 +187,35 @@ FSQ_DEV double fsq_div_by(double n, const FsqDivisor& k)
 // FAST = false: the plain division (same call sites, used by the exact build of a kernel)
 template <bool FAST> FSQ_DEV double fsq_div_sel(double n, const FsqDivisor& k) { return FAST ? fsq_div_by(n, k) : n / k.d; }
 
+// ---- 0.5 / sqrt(x) for the Givens rotations of qrsolv ------------------------------------------------------------
+// There x = .25 + .25 t^2 with |t| <= 1 (t = smaller / larger of two magnitudes), so x is in [0.25, 0.5] or NaN:
+// the compiler's sqrt (v_rsq + two Newton steps, wrapped in a subnormal pre-scale and a 0/inf pass-through) and its
+// division (v_div_scale x2 ... v_div_fixup) reduce to their cores, executed here as written - same instructions on
+// the same values, hence the same bits, at 18 instead of 31 instructions.  fsq_selftest_rotation compares the two.
+FSQ_DEV double fsq_half_over_sqrt_q(double x)
+{
+    // sqrt(x): g ~ sqrt(x), h ~ 1 / (2 sqrt(x))
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    double e = fsq_fma(-h, g, 0.5);
+    g = fsq_fma(g, e, g);
+    double d = fsq_fma(-g, g, x);
+    h = fsq_fma(h, e, h);
+    g = fsq_fma(d, h, g);
+    d = fsq_fma(-g, g, x);
+    g = fsq_fma(d, h, g);
+    // 0.5 / g, g in [0.5, 0.7072]
+    double r = __builtin_amdgcn_rcp(g);
+    e = fsq_fma(-g, r, 1.0);
+    r = fsq_fma(r, e, r);
+    e = fsq_fma(-g, r, 1.0);
+    r = fsq_fma(r, e, r);
+    double q = 0.5 * r;
+    const double rem = fsq_fma(-g, q, 0.5);
+    return fsq_fma(rem, r, q);
+}
+
 // ---- pow(x, 2.0) (e_pow.c): what numpy computes for a float64 SCALAR ** 2 ---------------------
 __device__ __noinline__ double fsq_pow2(double x)
 {

@@ -898,7 +898,32 @@ __global__ void kdivcheck(const double* __restrict__ num, const double* __restri
     if (fsq_bits(q0) != fsq_bits(q1)) atomicAdd(bad, 1ull);
 }
 long long g_last_slow = 0;
+
+__global__ void krotcheck(const double* __restrict__ t, long long n, unsigned long long* bad)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = .25 + .25 * t[i] * t[i];
+    const double a = 0.5 / fsq_sqrt(x), b = fsq_half_over_sqrt_q(x);
+    if (fsq_bits(a) != fsq_bits(b) && !(a != a && b != b)) atomicAdd(bad, 1ull);
+}
 }  // namespace
+
+extern "C" int fsq_selftest_rotation(const double* d_t, int64_t n, int64_t* mismatches, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (!d_t || !mismatches || n < 0) return FSQ_EINVAL;
+    unsigned long long* d_bad = nullptr;
+    FSQ_HIP_CHECK(hipMalloc((void**)&d_bad, 8));
+    FSQ_HIP_CHECK(hipMemsetAsync(d_bad, 0, 8, s));
+    if (n > 0) hipLaunchKernelGGL(krotcheck, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_t, (long long)n, d_bad);
+    unsigned long long h = 0;
+    FSQ_HIP_CHECK(hipMemcpyAsync(&h, d_bad, 8, hipMemcpyDeviceToHost, s));
+    FSQ_HIP_CHECK(hipStreamSynchronize(s));
+    (void)hipFree(d_bad);
+    *mismatches = (int64_t)h;
+    return FSQ_OK;
+}
 
 extern "C" int fsq_selftest_division(const double* d_num, const double* d_den, int64_t n, int64_t* mismatches, void* stream)
 {

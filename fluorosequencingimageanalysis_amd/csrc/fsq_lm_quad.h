@@ -419,7 +419,11 @@ FSQ_DEV void quadlm_qrsolv(QuadLm& q, double* scr, unsigned ipvt, double sqrt_pa
             const bool cnd = __builtin_fabs(rkk) < __builtin_fabs(sk);
             const double num = cnd ? rkk : sk, den = cnd ? sk : rkk;
             const double t = num / den;
+#ifdef FSQ_NO_ROT_SHORTCUT
             const double u = 0.5 / fsq_sqrt(.25 + .25 * t * t);
+#else
+            const double u = fsq_half_over_sqrt_q(.25 + .25 * t * t);          // == 0.5 / sqrt(.), see fsq_devmath.h
+#endif
             const double v = u * t;
             const double cosine = cnd ? v : u, sine = cnd ? u : v;
             const double nrkk = cosine * rkk + sine * sk;

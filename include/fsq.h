@@ -129,6 +129,9 @@ int fsq_phase_correlate(const double* d_ref, const double* d_reg, int n_pairs, i
  *   redone by the plain-division build of the kernel (env FSQ_DEBUG_FORCE_SLOW=k forces idx % k == 0 there).
  */
 int fsq_selftest_division(const double* d_num, const double* d_den, int64_t n, int64_t* mismatches, void* stream);
+/* fsq_selftest_rotation: qrsolv's 0.5 / sqrt(.25 + .25 t^2) (|t| <= 1) is evaluated by the cores of the compiler's
+ * sqrt and division expansions (fsq_devmath.h); counts the d_t[i] for which that differs from the plain expression. */
+int fsq_selftest_rotation(const double* d_t, int64_t n, int64_t* mismatches, void* stream);
 int64_t fsq_fit_last_slow_count(void);
 
 #ifdef __cplusplus

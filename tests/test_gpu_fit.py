@@ -126,3 +126,19 @@ def test_plain_division_kernel_gives_the_same_fits(env, monkeypatch):
     got2 = gpu_fit_rois(torch, N, rois)
     assert N.lib().fsq_fit_last_slow_count() == 0, "ordinary data must never leave the fast path"
     assert got2.tobytes() == got.tobytes()
+
+
+def test_rotation_shortcut_is_bit_identical(env):
+    """qrsolv's 0.5 / sqrt(.25 + .25 t^2): the range-specialised evaluation vs the plain expression for t in [-1, 1]
+    (dense random, tiny, the end points, and NaN)."""
+    import ctypes
+    torch, N, O = env
+    rng = np.random.default_rng(99)
+    n = 1 << 22
+    t = rng.uniform(-1.0, 1.0, n)
+    t[: 1 << 18] = np.ldexp(rng.random(1 << 18), rng.integers(-1070, 0, 1 << 18))       # down to subnormal t
+    t[1 << 18: (1 << 18) + 8] = [0.0, -0.0, 1.0, -1.0, np.nan, 2.0 ** -537, np.nextafter(1.0, 0), 5e-324]
+    d = torch.from_numpy(t).cuda()
+    bad = ctypes.c_int64(-1)
+    N.check(N.lib().fsq_selftest_rotation(d.data_ptr(), n, ctypes.byref(bad), torch.cuda.current_stream().cuda_stream), "selftest")
+    assert bad.value == 0
