@@ -19,6 +19,8 @@
 
 #include "fsq_common.h"
 #include "fsq_lm_quad.h"
+#include <mutex>
+#include <vector>
 
 namespace {
 
@@ -967,9 +969,43 @@ extern "C" int64_t fsq_fit_workspace_bytes(int64_t n)
 }
 
 // Host driver of the rounds.  Synchronises the stream every few rounds to read the queue sizes.
-int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_cand, int64_t n, int mode, bool from_image,
-                          FsqRow* d_rows, void* d_ws, int64_t ws_bytes, hipStream_t s)
+// High-priority streams for the late rounds.  Once few fits are left a round is a handful of small kernels whose
+// latency is the whole cost; when another stream (another lane of engine.LanePipeline) is busy with the large early
+// rounds of its own batch, the dispatcher would queue those small kernels behind whole large ones.  From the first
+// host look that finds fewer than FSQ_HIPRIO_BELOW live fits the rounds therefore continue on a stream of the highest
+// priority (the switch happens right after a stream synchronisation, so no event is needed).
+namespace {
+struct HiStream { hipStream_t s; int dev; bool busy; };
+std::mutex g_hi_mu;
+std::vector<HiStream> g_hi;
+hipStream_t hi_acquire()
 {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_hi_mu);
+    for (auto& h : g_hi)
+        if (!h.busy && h.dev == dev) { h.busy = true; return h.s; }
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return nullptr;
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest) != hipSuccess) return nullptr;
+    g_hi.push_back({st, dev, true});
+    return st;
+}
+void hi_release(hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(g_hi_mu);
+    for (auto& h : g_hi)
+        if (h.s == st) h.busy = false;
+}
+struct HiGuard { hipStream_t s = nullptr; ~HiGuard() { if (s) hi_release(s); } };
+}  // namespace
+
+int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_cand, int64_t n, int mode, bool from_image,
+                          FsqRow* d_rows, void* d_ws, int64_t ws_bytes, hipStream_t s_user)
+{
+    hipStream_t s = s_user;
+    HiGuard hi;
     if (ws_bytes < fsq_fit_workspace_bytes(n) || !d_ws) return FSQ_ENOMEM;
     if (n > 2000000000ll) return FSQ_ENOTIMPL;
     const size_t cap = (size_t)n + 64;
@@ -1011,12 +1047,13 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
     // t = 0 launches resident grids (8 waves per CU) that stride over the queue - measured 7% slower.
     long long full = (long long)cus * 8;
     int trips = 1, lm_first_cfg = FSQ_LMPAR_FIRST, sync_mask = 3;
-    long long two_pass_min = 524288;
+    long long two_pass_min = 524288, hiprio_below = 200000;
     {
         const char* e = getenv("FSQ_TRIPS_PER_BLOCK");
         if (e) trips = atoi(e);
         if ((e = getenv("FSQ_LMPAR_FIRST_ITERS")) != nullptr && atoi(e) >= 1 && atoi(e) <= 10) lm_first_cfg = atoi(e);
         if ((e = getenv("FSQ_TWO_PASS_MIN")) != nullptr) two_pass_min = atoll(e);
+        if ((e = getenv("FSQ_HIPRIO_BELOW")) != nullptr) hiprio_below = atoll(e);
         if ((e = getenv("FSQ_SYNC_EVERY")) != nullptr && atoi(e) >= 1) sync_mask = atoi(e) - 1;     // power of two
     }
     int h_cnt[12];
@@ -1077,10 +1114,18 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
             alive += slow_pending;
             if (getenv("FSQ_DEBUG_TRACE")) fprintf(stderr, "round %d: A=%lld B=%lld slow=%lld total_slow=%d\n", round, boundA, boundB, slow_pending, h_cnt[8]);
             if (boundA == 0 && boundB == 0 && slow_pending == 0) break;
+            if (!hi.s && alive < hiprio_below && n >= 4 * hiprio_below) {      // (small batches gain nothing)
+                hi.s = hi_acquire();
+                if (hi.s) s = hi.s;            // the user's stream is idle here: plain hand-over
+            }
         }
-        if (getenv("FSQ_DEBUG_MAX_ROUNDS") && round + 1 >= atoi(getenv("FSQ_DEBUG_MAX_ROUNDS"))) break;
+        if (getenv("FSQ_DEBUG_MAX_ROUNDS") && round + 1 >= atoi(getenv("FSQ_DEBUG_MAX_ROUNDS"))) {
+            FSQ_HIP_CHECK(hipStreamSynchronize(s));
+            break;
+        }
         if (round > 100000) return FSQ_EHIP;                 // cannot happen: every pass shrinks delta or accepts
     }
+    s = s_user;                     // the loop left right after a synchronisation: every round is complete
     hipLaunchKernelGGL(kfinish, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, c, d_rows);
     FSQ_HIP_CHECK(hipGetLastError());
     return FSQ_OK;
