@@ -52,6 +52,8 @@ _SIGS = {
                                       ctypes.c_void_p]),
     "fsq_phase_correlate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "fsq_mexican_hat": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "fsq_selftest_division": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                              ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p]),
     "fsq_selftest_rotation": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p]),

@@ -1025,7 +1025,6 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
     QB[1] = (double*)(ws + o); o += al256(cap * B_LEN * 8);
     int* cA[2] = {ctl + 0, ctl + 4};
     int* cB[2] = {ctl + 1, ctl + 5};
-    int* cS[2] = {ctl + 2, ctl + 6};
     int* cC[2] = {ctl + 3, ctl + 7};
     double* QC = (double*)(ws + o); o += al256(cap * C_LEN * 8);
     double* SQ = (double*)(ws + o); o += al256(cap * A_LEN * 8);

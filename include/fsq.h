@@ -121,6 +121,17 @@ int fsq_phase_correlate(const double* d_ref, const double* d_reg, int n_pairs, i
                         int upsample_factor, double* d_out4, void* stream);
 
 /*
+ * Spot photometry on the peak table: Spot.mexican_hat_photometry_metric, flexlibrary.py:172-210.
+ *   d_img   uint16[n_fields][H][W]; d_fhw int32[n][3] = (field, h, w) integer spot centres (the caller guarantees
+ *           0 <= field < n_fields; h, w may lie anywhere - the window is clipped like Spot.image_slice,
+ *           flexlibrary.py:140-146, and an empty brim gives nan like numpy.median([]))
+ *   d_out   double[n]: sum(crown) - len(crown) * median(brim); radius <= 15 (FSQ_ENOTIMPL beyond)
+ * Enqueues on the stream, does not synchronise.
+ */
+int fsq_mexican_hat(const uint16_t* d_img, int n_fields, int H, int W, const int32_t* d_fhw, int64_t n,
+                    int brim_size, int radius, double* d_out, void* stream);
+
+/*
  * Self-test hooks of the LM fit (no reference counterpart).
  * fsq_selftest_division: the fit kernel divides by shared divisors through a hoisted reciprocal that is
  *   bit-identical to the compiler's fp64 division inside a guarded operand range (fsq_devmath.h); this counts

@@ -45,6 +45,7 @@ int fsq_o_find_peptides(const uint16_t *img, int H, int W, int med_size, const i
 int fsq_o_fit_rois_u16(const uint16_t *rois, int n, int mode, int n_threads, FsqOFit *out);
 /* phase_correlate.phase_correlate: out4 = (row_shift, col_shift, error, diffphase) */
 int fsq_o_phase_correlate(const double *ref, const double *reg, int rows, int cols, int upsample, double *out4);
+double fsq_o_mexican_hat(const uint16_t *img, int H, int W, int h, int w, int brim, int radius);
 double fsq_o_enorm(const double *x, int n, int inc);
 double fsq_o_pairwise_sum(const double *a, long n);
 double fsq_o_numpy_sum(const double *a, long n);

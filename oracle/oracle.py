@@ -136,3 +136,19 @@ def phase_correlate(ref, reg, upsample_factor=1):
     if rc < 0:
         raise ValueError("oracle phase_correlate error %d" % rc)
     return tuple(out)
+
+
+def mexican_hat(img, hw, brim_size=6, radius=9):
+    """Spot.mexican_hat_photometry_metric (flexlibrary.py:172-210) for integer spot centres hw[n, 2]."""
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    H, W = img.shape
+    L = lib()
+    L.fsq_o_mexican_hat.restype = ctypes.c_double
+    L.fsq_o_mexican_hat.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 6
+    return np.array([L.fsq_o_mexican_hat(_p(img), H, W, int(h), int(w), int(brim_size), int(radius)) for h, w in hw])
+
+
+def gaussian_volume(fit7, scaling=10 ** 6):
+    """Spot.gaussian_volume_photometry_metric (flexlibrary.py:212-230): float(scaling) * A * sigma_h * sigma_w."""
+    f = np.asarray(fit7, dtype=np.float64)
+    return (float(scaling) * f[:, 3]) * f[:, 4] * f[:, 5]

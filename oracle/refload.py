@@ -86,3 +86,20 @@ def load_reference(textbook_qrsolv=False):
     r = Ref()
     r.mp, r.gf, r.pf, r.pc = mp, gf, pf, pc
     return r
+
+
+def load_flexlibrary(ref=None):
+    """flexlibrary.py on top of load_reference() - only the Spot photometry methods are used.
+    photutils and stepfitting_library are named at import time only; they are stood in for by empty modules (nothing of
+    theirs is called by the methods recorded in the goldens)."""
+    ref = ref or load_reference()
+    for name in ("photutils", "stepfitting_library"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    import scipy.ndimage
+    if "scipy.ndimage.measurements" not in sys.modules:
+        meas = types.ModuleType("scipy.ndimage.measurements")
+        meas.center_of_mass = scipy.ndimage.center_of_mass
+        sys.modules["scipy.ndimage.measurements"] = meas
+    ref.fl = load("flexlibrary", "flexlibrary.py")
+    return ref

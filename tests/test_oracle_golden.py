@@ -136,3 +136,16 @@ def test_errors():
         O.candidates(img, K=np.ones((4, 4), np.int64))          # pflib.py:236-239
     with pytest.raises(ValueError):
         O.find_peptides(img, radius=1)                          # pflib.py:431-432
+
+
+def test_photometry_matches_reference():
+    """Spot.mexican_hat_photometry_metric / gaussian_volume_photometry_metric (flexlibrary.py:172-230) as recorded from
+    the reference on its own peaks and on spots pushed against the image borders (tests/golden/photometry.npz)."""
+    g = np.load(os.path.join(GOLD, "photometry.npz"))
+    for name in g["names"]:
+        name = str(name)
+        _, img = load_field(name)
+        hw = g["hw_" + name]
+        assert np.array_equal(O.mexican_hat(img, hw), g["mexican_hat_b6_r9_" + name])
+        assert np.array_equal(O.mexican_hat(img, hw, 2, 4), g["mexican_hat_b2_r4_" + name])
+        assert np.array_equal(O.gaussian_volume(g["fit7_" + name]).view(np.uint64), g["gaussian_volume_" + name].view(np.uint64))
