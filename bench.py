@@ -75,16 +75,18 @@ def main():
     from fluorosequencingimageanalysis_amd import engine as E
     from fluorosequencingimageanalysis_amd import pflib
 
+    # synthetic fields first: the worker pool forks before this process has touched the GPU or opened a communicator
+    shape = (a.size, a.size)
+    env_rank = int(os.environ.get("RANK", "0"))
+    imgs = make_fields(range(env_rank * a.fields, (env_rank + 1) * a.fields), shape, a.spots)
+
     rank, world, local = D.init_from_env()
+    assert rank == env_rank
     assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
     assert torch.cuda.is_available(), "bench.py needs a GPU; the HIP path has no CPU fallback"
     local = local % torch.cuda.device_count()      # (more ranks than GPUs only in the gloo rehearsal of the N > 1 path)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-
-    shape = (a.size, a.size)
-    seeds = range(rank * a.fields, (rank + 1) * a.fields)
-    imgs = make_fields(seeds, shape, a.spots)
     d_img = E.to_device_u16(imgs, dev)
     prm = E.detect_params(5, pflib.default_correlation_matrix, 2)
 

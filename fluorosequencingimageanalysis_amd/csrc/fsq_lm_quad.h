@@ -391,9 +391,10 @@ FSQ_DEV void quadlm_scatter(QuadLm& q, double* scr, unsigned ipvt, const double*
 template <bool ALIASED, int STRIDE>
 FSQ_DEV void quadlm_qrsolv(QuadLm& q, double* scr, unsigned ipvt, double sqrt_par)
 {
-    // Branch-free on purpose: the two `break`s of the reference (mpfit.py:1921-1922, 1932-1933) become
-    // select masks, so the 28 rotations form one basic block and independent rotations (row j+1 trails
-    // row j by one column) overlap in the VALU pipeline.
+    // Fully unrolled with static register indices.  The two `break`s of the reference (mpfit.py:1921-1922,
+    // 1932-1933) are lane predicates (default) or, with -DFSQ_QRSOLV_SELECTS, per-element selects that keep the 28
+    // rotations in one basic block - the form that was faster at one wave per SIMD; at two it costs 3 % (a quarter
+    // of the instructions of a pass were v_cndmask).
     const int n = FSQ_NP;
     double wa[FSQ_NP], xsave[FSQ_NP];
 #pragma unroll
@@ -402,6 +403,7 @@ FSQ_DEV void quadlm_qrsolv(QuadLm& q, double* scr, unsigned ipvt, double sqrt_pa
         for (int i = j + 1; i < n; i++) q.r[i][j] = q.r[j][i];
 #pragma unroll
     for (int j = 0; j < n; j++) { xsave[j] = q.r[j][j]; wa[j] = q.qtf[j]; }
+#ifdef FSQ_QRSOLV_SELECTS
     bool jgo = true;                                     // false once `diag[l] == 0: break` has fired
 #pragma unroll
     for (int j = 0; j < n; j++) {
@@ -444,6 +446,53 @@ FSQ_DEV void quadlm_qrsolv(QuadLm& q, double* scr, unsigned ipvt, double sqrt_pa
         q.sdiag[j] = jgo ? q.r[j][j] : q.sdiag[j];
         if (!ALIASED) q.r[j][j] = jgo ? xsave[j] : q.r[j][j];
     }
+#else
+    // The reference's two `break`s (mpfit.py:1921-1922, 1932-1933) as lane predicates: a lane that has left a loop
+    // simply sits out the rest of it under the exec mask (no per-element selects); the rotation code itself stays
+    // straight-line, and with two waves per SIMD the short predicated blocks cost no issue slots.
+    bool jgo = true;                                     // false once `diag[l] == 0: break` has fired
+#pragma unroll
+    for (int j = 0; j < n; j++) {
+        const double dl = sqrt_par * q.dgp[j];          // (temp * diag)[ipvt[j]]
+        jgo = jgo && !(dl == 0);
+        if (jgo) {
+#pragma unroll
+            for (int k = j; k < n; k++) q.sdiag[k] = (k == j) ? dl : 0.0;
+            double qtbpj = 0.;
+            bool kgo = true;                             // false once `sdiag[k] == 0: break` has fired
+#pragma unroll
+            for (int k = j; k < n; k++) {
+                const double sk = q.sdiag[k];
+                kgo = kgo && !(sk == 0);
+                if (kgo) {
+                    const double rkk = q.r[k][k];
+                    const bool cnd = __builtin_fabs(rkk) < __builtin_fabs(sk);
+                    const double num = cnd ? rkk : sk, den = cnd ? sk : rkk;
+                    const double t = num / den;
+#ifdef FSQ_NO_ROT_SHORTCUT
+                    const double u = 0.5 / fsq_sqrt(.25 + .25 * t * t);
+#else
+                    const double u = fsq_half_over_sqrt_q(.25 + .25 * t * t);          // == 0.5 / sqrt(.), see fsq_devmath.h
+#endif
+                    const double v = u * t;
+                    const double cosine = cnd ? v : u, sine = cnd ? u : v;
+                    q.r[k][k] = cosine * rkk + sine * sk;
+                    const double temp = cosine * wa[k] + sine * qtbpj;
+                    qtbpj = -sine * wa[k] + cosine * qtbpj;
+                    wa[k] = temp;
+#pragma unroll
+                    for (int i = k + 1; i < n; i++) {
+                        const double rik = q.r[i][k], si = q.sdiag[i];
+                        q.r[i][k] = cosine * rik + sine * si;
+                        q.sdiag[i] = -sine * rik + cosine * si;
+                    }
+                }
+            }
+            q.sdiag[j] = q.r[j][j];
+            if (!ALIASED) q.r[j][j] = xsave[j];
+        }
+    }
+#endif
     int nsing = n;
 #pragma unroll
     for (int j = n - 1; j >= 0; j--)
