@@ -451,22 +451,47 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                         }
 #pragma unroll
                         for (int i = 0; i < FSQ_NPIX; i++) col[i] = col[i] - fsq_div_sel<FAST>(REFL(i) * s, kj);
-                        if (!is_f) {
-                            double rk = QL(Q_RDIAG, k);
-                            if (rk != 0) {
-                                double temp = col[0] / rk;
-                                rk = rk * fsq_sqrt(np_max2(1. - fsq_pow2(temp), 0.));
-                                temp = rk / QL(Q_WA, k);
-                                if ((0.05 * temp * temp) <= FSQ_MACHEP) {
-                                    rk = fsq_sqrt(dot_regcol_from1(col, len));
-                                    QL(Q_WA, k) = rk;
-                                }
-                                QL(Q_RDIAG, k) = rk;
-                            }
-                        }
                     }
                     if (is_f) QL(Q_QTF, j) = col[0];
                     else if (slot < 7 && nib_get(pos, slot) > j) QL(Q_R, j * 7 + slot) = col[0];
+                }
+                // Norm down-dating of the live columns (mpfit.py:1810-1820).  It is scalar work per column (a divide, a
+                // pow, a sqrt, a divide), and at step j only the 6 - j columns at positions > j are live, scattered over
+                // the 8 register slots of the quad: instead of running it slot by slot (2 passes per step whatever is
+                // live) the lanes take the live POSITIONS in order - lane c4 position j+1+c4, then j+5+c4 - reading the
+                // column's new leading element R(j, .) from LDS: 8 passes per factorization instead of 14.  The rare full
+                // recomputation of a norm needs the column itself, so that goes back to the lane that holds it.
+                WAVE_SYNC();
+                unsigned long long redo[2] = {0ull, 0ull};
+#pragma unroll
+                for (int sub = 0; sub < 2; sub++) {
+                    const int p = j + 1 + c4 + 4 * sub;
+                    bool need = false;
+                    if (p < n7 && !broken && ajj0 != 0) {
+                        double rk = QL(Q_RDIAG, p);
+                        if (rk != 0) {
+                            double temp = QL(Q_R, j * 7 + nib_get(ipvt, p)) / rk;
+                            rk = rk * fsq_sqrt(np_max2(1. - fsq_pow2(temp), 0.));
+                            temp = rk / QL(Q_WA, p);
+                            if ((0.05 * temp * temp) <= FSQ_MACHEP) need = true;
+                            else QL(Q_RDIAG, p) = rk;
+                        }
+                    }
+                    redo[sub] = __ballot(need);
+                }
+                if (redo[0] | redo[1]) {
+#pragma unroll
+                    for (int pass = 0; pass < 2; pass++) {
+                        const int slot = c4 + 4 * pass;
+                        const double* col = pass ? cb : ca;
+                        const int k = (slot < 7) ? nib_get(pos, slot) : 0;
+                        const int idx = k - j - 1;
+                        if (slot < 7 && idx >= 0 && ((redo[idx >> 2] >> (qbase + (idx & 3))) & 1ull)) {
+                            const double rk = fsq_sqrt(dot_regcol_from1(col, len));
+                            QL(Q_WA, k) = rk;
+                            QL(Q_RDIAG, k) = rk;
+                        }
+                    }
                 }
                 if (!broken) QL(Q_RDIAG, j) = QL(Q_TMP, 0);
                 QL(Q_R, j * 7 + lj) = QL(Q_RDIAG, j);               // fjac[j, lj] = rdiag[j] (mpfit.py:1123)
