@@ -69,6 +69,7 @@ struct Ctx {
     FitStat* stat;            // [n]
     long long cap;            // queue capacity (positions)
     int* slow_total;          // statistics: fits that went through the plain-division kernel
+    int force_redo;           // debug: take qrfac's norm re-computation branch at every step (FSQ_DEBUG_FORCE_NORM_RECOMPUTE)
     int force_slow_mod;       // debug: route every fit with idx % mod == 0 through the plain-division kernel
 };
 
@@ -473,7 +474,7 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                             double temp = QL(Q_R, j * 7 + nib_get(ipvt, p)) / rk;
                             rk = rk * fsq_sqrt(np_max2(1. - fsq_pow2(temp), 0.));
                             temp = rk / QL(Q_WA, p);
-                            if ((0.05 * temp * temp) <= FSQ_MACHEP) need = true;
+                            if ((0.05 * temp * temp) <= FSQ_MACHEP || c.force_redo) need = true;
                             else QL(Q_RDIAG, p) = rk;
                         }
                     }
@@ -1057,6 +1058,8 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
     {
         const char* e = getenv("FSQ_DEBUG_FORCE_SLOW");
         c.force_slow_mod = e ? atoi(e) : 0;
+        e = getenv("FSQ_DEBUG_FORCE_NORM_RECOMPUTE");
+        c.force_redo = (e && atoi(e)) ? 1 : 0;
     }
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

@@ -265,6 +265,11 @@ static void residual(const double *data, const double *p, double *r, int *nfev)
 
 /* ================================================================= qrfac  (mpfit.py:1748-1822)
  * a is m x n row-major (stride n). */
+/* test switch: take the norm re-computation branch of qrfac (mpfit.py:1817-1820) at every step - the branch is
+ * practically unreachable on image data, this is how the GPU's implementation of it gets compared */
+static int g_force_norm_recompute = 0;
+void fsq_o_set_force_norm_recompute(int on) { g_force_norm_recompute = on; }
+
 void fsq_o_qrfac(double *a, int m, int n, int pivot, int *ipvt, double *rdiag, double *acnorm)
 {
     double wa[16];
@@ -302,7 +307,7 @@ void fsq_o_qrfac(double *a, int m, int n, int pivot, int *ipvt, double *rdiag, d
                     double temp = a[(size_t)j * n + lk] / rdiag[k];
                     rdiag[k] = rdiag[k] * sqrt(np_max2(1. - fsq_ref_pow2(temp), 0.));   /* :1816 scalar **2 */
                     temp = rdiag[k] / wa[k];
-                    if ((0.05 * temp * temp) <= MACHEP) {
+                    if ((0.05 * temp * temp) <= MACHEP || g_force_norm_recompute) {
                         rdiag[k] = enorm_s(a + (size_t)(j + 1) * n + lk, m - j - 1, n);
                         wa[k] = rdiag[k];
                     }

@@ -31,6 +31,7 @@ int fsq_o_fit_roi(const int64_t *roi25, int mode, FsqOFit *out);
 void fsq_o_model(const double *p7, double *g25);
 void fsq_o_qrfac(double *a, int m, int n, int pivot, int *ipvt, double *rdiag, double *acnorm);
 double fsq_o_illumina_s_n(const int64_t *roi25);
+void fsq_o_set_force_norm_recompute(int on);
 void fsq_o_fit_metrics(const int64_t *roi25, const double *p7, int h, int w, FsqORow *row);
 int fsq_o_consolidate(const FsqORow *rows, int n, int H, int W, double r2_thr, int radius, int py2,
                       int32_t *keep_idx, int32_t *key_hw);

@@ -142,3 +142,24 @@ def test_rotation_shortcut_is_bit_identical(env):
     bad = ctypes.c_int64(-1)
     N.check(N.lib().fsq_selftest_rotation(d.data_ptr(), n, ctypes.byref(bad), torch.cuda.current_stream().cuda_stream), "selftest")
     assert bad.value == 0
+
+
+def test_norm_recomputation_branch(env, monkeypatch):
+    """qrfac's re-computation of a down-dated column norm (mpfit.py:1817-1820) never fires on image data (0 events in
+    the golden fields), so it is forced on both sides: the GPU kernel (the lane that owns the column recomputes it from
+    its registers) and the oracle must still agree bit for bit - on a different trajectory than the unforced fit."""
+    torch, N, O = env
+    g, img = load_field("f3_hard_256")
+    rois = rois_of(img, g["candidates"])
+    monkeypatch.setenv("FSQ_DEBUG_FORCE_NORM_RECOMPUTE", "1")
+    O.lib().fsq_o_set_force_norm_recompute(1)
+    try:
+        got = gpu_fit_rois(torch, N, rois)
+        ref = O.fit_rois(rois, mode=0, n_threads=16)
+    finally:
+        O.lib().fsq_o_set_force_norm_recompute(0)
+        monkeypatch.delenv("FSQ_DEBUG_FORCE_NORM_RECOMPUTE")
+    p = np.stack([got[k] for k in ("H", "A", "p2", "p3", "sigma_h", "sigma_w", "theta")], axis=1)
+    assert bits_equal(p, ref["p"]).all()
+    assert np.array_equal(got["status"], ref["status"]) and np.array_equal(got["nfev"], ref["nfev"])
+    assert not bits_equal(p, g["params"]).all(), "the forced branch should change some trajectories"
