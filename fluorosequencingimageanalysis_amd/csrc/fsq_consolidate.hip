@@ -27,70 +27,106 @@ __global__ void __launch_bounds__(64) k5_consolidate(FsqRow* __restrict__ rows, 
     FsqRow* R = rows + off;
     const double rr = (double)(radius * radius);
 
-    // dict insertion (setdefault, pflib.py:477): survivors of the R^2 filter (NaN passes, :466)
-    for (int i = lane; i < cnt; i += 64) {
-        R[i].key_h = -1; R[i].key_w = -1;
-        if (!(R[i].r2 < r2_thr)) grid[(size_t)R[i].h * W + R[i].w] = i;
+    // dict insertion (setdefault, pflib.py:477): survivors of the R^2 filter (NaN passes, :466).  Their indices are
+    // also compacted, in order, into this field's slice of `keep` (scratch until the final list is written): the two
+    // sequential walks below then touch ~15 % of the candidates and read each survivor's row ONCE, 64 rows at a time,
+    // instead of chasing two dependent global loads per candidate.
+    int* surv = keep + off;
+    int nsurv = 0;
+    for (int base = 0; base < cnt; base += 64) {
+        const int i = base + lane;
+        bool ok = false;
+        if (i < cnt) {
+            R[i].key_h = -1; R[i].key_w = -1;
+            ok = !(R[i].r2 < r2_thr);
+            if (ok) grid[(size_t)R[i].h * W + R[i].w] = i;
+        }
+        const unsigned long long m = __ballot(ok);
+        if (ok) surv[nsurv + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        nsurv += __popcll(m);
     }
     __syncthreads();
 
     // consolidation, pflib.py:479-512
-    const int win = 2 * radius + 5;
-    for (int i = 0; i < cnt; i++) {
-        const int h = R[i].h, w = R[i].w;
-        if (grid[(size_t)h * W + w] != i) continue;    // filtered out or already deleted (wave-uniform)
-        const double h0 = R[i].h0, w0 = R[i].w0, r2i = R[i].r2;
-        const int h_lo = max(0, h - radius - 2), h_hi = min(h + radius + 3, H);
-        const int w_lo = max(0, w - radius - 2), w_hi = min(w + radius + 3, W);
-        const int ww = w_hi - w_lo, ncell = (h_hi - h_lo) * ww;
-        bool dead = false;
-        for (int base = 0; base < ncell && !dead; base += 64) {
-            int c = base + lane;
-            bool rival = false, lose = false;
-            size_t cell = 0;
-            if (c < ncell) {
-                int hd = h_lo + c / ww, wd = w_lo + c % ww;
-                cell = (size_t)hd * W + wd;
-                int k = grid[cell];
-                if (k >= 0 && !(hd == h && wd == w)) {
-                    double dh = h0 - R[k].h0, dw = w0 - R[k].w0;
-                    if (!(fsq_pow2(dh) + fsq_pow2(dw) > rr)) {       // numpy scalar **2, pflib.py:505
-                        rival = true;
-                        lose = !(r2i > R[k].r2);                    // pflib.py:508
+    for (int sbase = 0; sbase < nsurv; sbase += 64) {
+        const int nb = min(64, nsurv - sbase);
+        int my_i = -1, my_h = 0, my_w = 0;
+        double my_h0 = 0., my_w0 = 0., my_r2 = 0.;
+        if (lane < nb) {
+            my_i = surv[sbase + lane];
+            my_h = R[my_i].h; my_w = R[my_i].w; my_h0 = R[my_i].h0; my_w0 = R[my_i].w0; my_r2 = R[my_i].r2;
+        }
+        for (int j = 0; j < nb; j++) {
+            const int i = __shfl(my_i, j), h = __shfl(my_h, j), w = __shfl(my_w, j);
+            if (grid[(size_t)h * W + w] != i) continue;        // already deleted by an earlier candidate (wave-uniform)
+            const double h0 = __shfl(my_h0, j), w0 = __shfl(my_w0, j), r2i = __shfl(my_r2, j);
+            const int h_lo = max(0, h - radius - 2), h_hi = min(h + radius + 3, H);
+            const int w_lo = max(0, w - radius - 2), w_hi = min(w + radius + 3, W);
+            const int ww = w_hi - w_lo, ncell = (h_hi - h_lo) * ww;
+            bool dead = false;
+            for (int base = 0; base < ncell && !dead; base += 64) {
+                int c = base + lane;
+                bool rival = false, lose = false;
+                size_t cell = 0;
+                if (c < ncell) {
+                    int hd = h_lo + c / ww, wd = w_lo + c % ww;
+                    cell = (size_t)hd * W + wd;
+                    int k = grid[cell];
+                    if (k >= 0 && !(hd == h && wd == w)) {
+                        double dh = h0 - R[k].h0, dw = w0 - R[k].w0;
+                        if (!(fsq_pow2(dh) + fsq_pow2(dw) > rr)) {       // numpy scalar **2, pflib.py:505
+                            rival = true;
+                            lose = !(r2i > R[k].r2);                    // pflib.py:508
+                        }
                     }
                 }
+                unsigned long long mlose = __ballot(lose);
+                int first = mlose ? (__ffsll((long long)mlose) - 1) : 64;
+                if (rival && lane < first) grid[cell] = -1;             // rivals with smaller R^2 die
+                if (mlose) {
+                    if (lane == 0) grid[(size_t)h * W + w] = -1;        // the candidate itself dies, scan stops
+                    dead = true;
+                }
+                __syncthreads();
             }
-            unsigned long long mlose = __ballot(lose);
-            int first = mlose ? (__ffsll((long long)mlose) - 1) : 64;
-            if (rival && lane < first) grid[cell] = -1;             // rivals with smaller R^2 die
-            if (mlose) {
-                if (lane == 0) grid[(size_t)h * W + w] = -1;        // the candidate itself dies, scan stops
-                dead = true;
-            }
-            __syncthreads();
         }
-        (void)win;
     }
 
-    // re-key, pflib.py:514-519 (sequential: the assert looks at the dict as it is at that moment)
+    // re-key, pflib.py:514-519.  Whether an entry is still alive cannot change during this loop (entries only ever
+    // move into EMPTY cells), so liveness, the rounded key and the key write are done 64 survivors at a time; only
+    // the entries whose key actually moves are then replayed one by one in index order, because the reference's
+    // assert looks at the dict as it is at that moment.
     __shared__ int s_assert;
-    if (lane == 0) {
-        int bad = 0;
-        for (int i = 0; i < cnt; i++) {
-            size_t g = (size_t)R[i].h * W + R[i].w;
-            if (grid[g] != i || R[i].key_h >= 0) continue;          // not alive (or a moved entry parked here)
-            int hr = (int)round_key(R[i].h0, py2), wr = (int)round_key(R[i].w0, py2);
-            R[i].key_h = hr; R[i].key_w = wr;
-            if (hr != R[i].h || wr != R[i].w) {
+    if (lane == 0) s_assert = 0;
+    __syncthreads();
+    for (int sbase = 0; sbase < nsurv; sbase += 64) {
+        const int s_ = sbase + lane;
+        bool moved = false;
+        int i = -1, hr = 0, wr = 0;
+        size_t g = 0;
+        if (s_ < nsurv) {
+            i = surv[s_];
+            g = (size_t)R[i].h * W + R[i].w;
+            if (grid[g] == i) {
+                hr = (int)round_key(R[i].h0, py2); wr = (int)round_key(R[i].w0, py2);
+                R[i].key_h = hr; R[i].key_w = wr;
+                moved = (hr != R[i].h) || (wr != R[i].w);
+            }
+        }
+        unsigned long long mm = __ballot(moved);
+        while (mm) {
+            const int b = __ffsll((long long)mm) - 1;
+            mm &= mm - 1;
+            if (lane == b) {
                 grid[g] = -1;
                 if (hr >= 0 && hr < H && wr >= 0 && wr < W) {
                     size_t g2 = (size_t)hr * W + wr;
-                    if (grid[g2] >= 0) bad = 1;                     // assert (h_0_r, w_0_r) not in pixel_bins
+                    if (grid[g2] >= 0) s_assert = 1;                 // assert (h_0_r, w_0_r) not in pixel_bins
                     else grid[g2] = i;
                 }
             }
+            __syncthreads();
         }
-        s_assert = bad;
     }
     __syncthreads();
 
