@@ -34,8 +34,13 @@ def _make(seed_shape):
 def make_fields(seeds, shape, n_spots):
     import multiprocessing as mp
     n = min(16, os.cpu_count() or 1)
-    with mp.get_context("fork").Pool(n) as pool:
-        return np.stack(pool.map(_make, [(s, shape, n_spots) for s in seeds], chunksize=8))
+    pool = mp.get_context("fork").Pool(n)
+    try:
+        out = np.stack(pool.map(_make, [(s, shape, n_spots) for s in seeds], chunksize=8))
+    finally:
+        pool.close()        # let the workers leave on their own: Pool.terminate() SIGTERMs them, and under rocprofv3
+        pool.join()         # the profiler's signal handler in a forked worker can block that forever
+    return out
 
 
 def cpu_baseline(imgs, cand, counts, offsets, n_threads):
