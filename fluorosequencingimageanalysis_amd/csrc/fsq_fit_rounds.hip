@@ -4,23 +4,29 @@
 // regular) and mpfit's inner loop (lmpar with 0..10 qrsolv passes + a trial evaluation, scalar and wildly
 // irregular: a quarter of the lmpar calls run all 10 passes, most run 0-1, steps get rejected and retried).
 // Run in lockstep inside one wave the irregular part leaves 70% of the lanes idle (measured).  So every
-// candidate keeps its solver state in HBM (one ~0.8 KB record, AoS) and the fit advances in rounds:
+// candidate keeps its solver state in HBM (queue records in structure-of-arrays form, see below) and the fit
+// advances in rounds:
 //   kA  "Jacobian round"  quad-cooperative (4 lanes per fit, columns in registers, see fsq_lm_quad.h):
 //                         fdjac2 + qrfac + Q^T f + gradient test            mpfit.py:1064-1160
 //   kB  "step round"      one lane per fit, R in registers: lmpar, bounded step, trial evaluation,
 //                         trust-region update, convergence tests             mpfit.py:1163-1335
-// Each kernel walks a list of candidate indices and appends every candidate to the list of the kernel it
-// needs next (accepted step -> kA, rejected step -> kB again, terminated -> done), so every wave of every
-// launch is full, whatever the iteration counts are.  Kernel boundaries give the inter-workgroup
-// visibility; no data-path collective, no atomics other than the list tails.
-// Arithmetic: identical, operation for operation, to fsq_lm_core.h (the reference's mpfit order).
+//                         (first pass: 3 lmpar iterations, unfinished fits parked in queue C; second
+//                         instantiation resumes those)
+// Each kernel takes one queue entry group per block (16 fits in kA, 64 in kB) and appends every fit to the
+// queue of the kernel it needs next (accepted step -> kA, rejected step -> kB again, terminated -> done), so
+// every wave of every launch is full, whatever the iteration counts are.  Kernel boundaries give the
+// inter-workgroup visibility; no data-path collective, no atomics other than one per wave per queue tail.
+// Arithmetic: identical, operation for operation, to fsq_lm_core.h (the reference's mpfit order); where an
+// operation is evaluated by a cheaper instruction sequence (hoisted-reciprocal division, range-specialised
+// 0.5/sqrt) the sequence is the compiler's own with its no-op wrappers removed - see fsq_devmath.h.
 #include <atomic>
 #include <cstdlib>
 
-#include "fsq_common.h"
-#include "fsq_lm_quad.h"
 #include <mutex>
 #include <vector>
+
+#include "fsq_common.h"
+#include "fsq_lm_quad.h"
 
 namespace {
 
@@ -45,8 +51,9 @@ __device__ unsigned long long g_rphase[16];
 //   queue A record (input of kA):  idx | x[7] | diag[7] | llim1 fnorm par delta xnorm | niter,nfev      21 x 8 B
 //   queue B record (input of kB):  the same 21 + gnorm | ipvt | qtf[7] | sdiag[7] | R upper[28]          65 x 8 B
 //   queue C record (kB, resumed):  the same 65 + parl paru fp | lmpar iterations done                    69 x 8 B
-// Indexed by candidate: fvec[25] (written on acceptance, read by kA), the final result, the ROI statistics.
-// The ROI pixels are re-read from the image (5 rows of 10 B) - they never change.
+//   slow queue (plain-division kA): copies of queue-A records of fits that left the guarded operand ranges
+// Indexed by candidate: a compact 64-byte copy of the 25 ROI pixels (kinit), fvec[25] (written on acceptance,
+// read by kA), the final result, the ROI statistics.
 enum { A_IDX = 0, A_X = 1, A_DIAG = 8, A_LLIM1 = 15, A_FNORM = 16, A_PAR = 17, A_DELTA = 18, A_XNORM = 19, A_ITER = 20,
        A_LEN = 21,
        B_GNORM = 21, B_IPVT = 22, B_QTF = 23, B_SDIAG = 30, B_R = 37, B_LEN = 65,

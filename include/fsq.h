@@ -81,11 +81,15 @@ int fsq_detect(const uint16_t* d_img, int n_fields, int H, int W, const FsqDetec
 /* Workspace bytes the fit entry points need for n candidates. */
 int64_t fsq_fit_workspace_bytes(int64_t n);
 
-/* LM-fit n candidates (any mix of fields); d_rows[n] out. Enqueue only.
+/* LM-fit n candidates (any mix of fields); d_rows[n] out.
  * mode: FSQ_MODE_REF / FSQ_MODE_TEXTBOOK.  The default engine advances all candidates in rounds
- * (Jacobian round / step round, see csrc/fsq_fit_rounds.hip) and synchronises the stream every few
- * rounds to read the list sizes; | FSQ_ENGINE_LANE or | FSQ_ENGINE_QUAD select the two single-launch
- * persistent engines instead (identical results; kept for A/B timing). */
+ * (Jacobian round / step round, see csrc/fsq_fit_rounds.hip): the call drives those rounds from the calling
+ * host thread and synchronises the stream every few rounds to read the queue sizes, so it returns when the
+ * last round has run (large batches finish their last, nearly empty rounds on an internal highest-priority
+ * stream); only the final row-writing kernel is merely enqueued on `stream`.  Thread-safe: concurrent calls
+ * with different workspaces / streams are independent (engine.LanePipeline).
+ * | FSQ_ENGINE_LANE or | FSQ_ENGINE_QUAD select the two single-launch persistent engines instead (identical
+ * results; kept for A/B timing). */
 int fsq_fit_candidates(const uint16_t* d_img, int n_fields, int H, int W, const int32_t* d_cand, int64_t n,
                        int mode, FsqRow* d_rows, void* d_workspace, int64_t workspace_bytes, void* stream);
 
