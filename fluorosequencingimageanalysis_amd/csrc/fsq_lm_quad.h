@@ -6,13 +6,15 @@
 //     c+4 in REGISTERS (2 x 25 doubles) - fdjac2's seven model evaluations, the column norms, the
 //     Householder updates and Q^T f all run column-parallel with no cross-lane sums, because every
 //     python sum() of the reference runs down a column;
-//   * the pivot column (the reflector) is broadcast inside the quad with ds_bpermute each step and
-//     the column registers shift up one row per step, so all register indices stay static;
+//   * the pivot column (the reflector) is handed round the quad each step - with ds_bpermute in the persistent
+//     engine (fsq_fit_quad.hip), through LDS by the lane that owns it in the rounds engine (fsq_fit_rounds.hip) -
+//     and the column registers shift up one row per step, so all register indices stay static;
 //   * the 7x7 part (R, lmpar, qrsolv, the trust-region bookkeeping) lives in LDS, one 8-byte slot per
 //     quad per element ([element][quad] layout: the 4 lanes of a quad broadcast-read the same address,
 //     different quads hit different banks) and is executed redundantly by the 4 lanes;
-//   * a wave advances all its 16 fits by one outer LM iteration per loop trip and refills finished
-//     quads from a global queue, so the 1..200 iteration spread costs no idle lanes.
+//   * persistent engine: a wave advances all its 16 fits by one outer LM iteration per loop trip and refills
+//     finished quads from a global queue, so the 1..200 iteration spread costs no idle lanes; rounds engine: only
+//     the Jacobian round runs in this layout, the 7x7 part runs one lane per fit (QuadLm below).
 #pragma once
 #include "fsq_lm_core.h"
 
