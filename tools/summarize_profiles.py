@@ -21,6 +21,17 @@ if f:
         md.append("| `%s` | %s | %.2f | %.1f | %s |" % (r["Name"][:80], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                      float(r["AverageNs"]) / 1e3, r["Percentage"]))
     out["kernel_stats"] = ks
+    # the "kernel" bench.py prices in its roofline is the whole LM fit: kinit + rounds of kA / kB + kfinish
+    allk = [{"name": r["Name"], "calls": int(r["Calls"]), "total_ms": float(r["TotalDurationNs"]) / 1e6} for r in rows]
+    fitk = [k for k in allk if any(t in k["name"] for t in ("kinit", "kA_jacobian", "kB_step", "kfinish"))]
+    launches = sum(k["calls"] for k in allk if "kinit" in k["name"])
+    if launches:
+        per = sum(k["total_ms"] for k in fitk) / launches
+        out["fit_kernels_ms_per_launch"] = per
+        out["fit_launches"] = launches
+        md += ["", "LM fit as one unit (kinit + every kA_jacobian / kB_step round + kfinish): %.1f ms of kernel time per launch over "
+               "%d launches - bench.py's `roofline.launch_ms` (HIP events around the same launches) adds the host gaps "
+               "between rounds and, with two lanes, the time a lane's kernels wait for the other lane's." % (per, launches)]
 for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     f = glob.glob(base + "/%s/*/*counter_collection.csv" % tag)
     if not f:
