@@ -64,7 +64,7 @@ def cpu_baseline(imgs, cand, counts, offsets, n_threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--fields", type=int, default=1024, help="fields per GPU")
     ap.add_argument("--size", type=int, default=512)
