@@ -56,6 +56,7 @@ _SIGS = {
                                        ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "fsq_selftest_division": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                              ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p]),
+    "fsq_selftest_exp": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p]),
     "fsq_selftest_rotation": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p]),
     "fsq_fit_last_slow_count": (ctypes.c_int64, []),
 }

@@ -944,6 +944,44 @@ __global__ void krotcheck(const double* __restrict__ t, long long n, unsigned lo
 }
 }  // namespace
 
+namespace {
+__global__ void kexpcheck(const double* __restrict__ x, long long n, unsigned long long* bad)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool flag = false;
+    const double a = fsq_exp(x[i]), b = fsq_exp_bf(x[i], &flag);
+    FsqExpA h;
+    const unsigned ix = fsq_exp_bf_a(x[i], &h);
+    bool flag2 = false;
+    const double c = fsq_exp_bf_b(h, FSQ_EXP_TAB[ix], FSQ_EXP_TAB[ix + 1], &flag2);
+    const double ax = __builtin_fabs(x[i]);
+    const bool expect_flag = (ax >= 512.0 && ax < 1024.0);
+    bool wrong = (flag != expect_flag) || (flag2 != expect_flag);
+    if (!expect_flag) {
+        const bool nan_ok = (a != a) && (b != b) && (c != c);
+        wrong = wrong || (!nan_ok && (fsq_bits(a) != fsq_bits(b) || fsq_bits(a) != fsq_bits(c)));
+    }
+    if (wrong) atomicAdd(bad, 1ull);
+}
+}  // namespace
+
+extern "C" int fsq_selftest_exp(const double* d_x, int64_t n, int64_t* mismatches, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (!d_x || !mismatches || n < 0) return FSQ_EINVAL;
+    unsigned long long* d_bad = nullptr;
+    FSQ_HIP_CHECK(hipMalloc((void**)&d_bad, 8));
+    FSQ_HIP_CHECK(hipMemsetAsync(d_bad, 0, 8, s));
+    if (n > 0) hipLaunchKernelGGL(kexpcheck, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_x, (long long)n, d_bad);
+    unsigned long long h = 0;
+    FSQ_HIP_CHECK(hipMemcpyAsync(&h, d_bad, 8, hipMemcpyDeviceToHost, s));
+    FSQ_HIP_CHECK(hipStreamSynchronize(s));
+    (void)hipFree(d_bad);
+    *mismatches = (int64_t)h;
+    return FSQ_OK;
+}
+
 extern "C" int fsq_selftest_rotation(const double* d_t, int64_t n, int64_t* mismatches, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;

@@ -163,3 +163,24 @@ def test_norm_recomputation_branch(env, monkeypatch):
     assert bits_equal(p, ref["p"]).all()
     assert np.array_equal(got["status"], ref["status"]) and np.array_equal(got["nfev"], ref["nfev"])
     assert not bits_equal(p, g["params"]).all(), "the forced branch should change some trajectories"
+
+
+def test_branch_free_exp_is_bit_identical(env):
+    """fsq_exp_bf (selects instead of branches, used by the Jacobian kernel) vs fsq_exp (the branching restatement of
+    glibc's exp, itself pinned by tests/test_refmath.py on the CPU side): the model's range [-80, 0] densely, the whole
+    double range sparsely, tiny / huge / non-finite arguments; 512 <= |x| < 1024 must raise the range flag instead."""
+    import ctypes
+    torch, N, O = env
+    rng = np.random.default_rng(7)
+    n = 1 << 22
+    x = -rng.uniform(0.0, 80.0, n)
+    k = 1 << 19
+    x[:k] = rng.uniform(-1100.0, 1100.0, k)
+    x[k:2 * k] = rng.choice([-1.0, 1.0], k) * np.ldexp(rng.random(k) + 1.0, rng.integers(-1074, 1023, k))
+    sp = [0.0, -0.0, np.inf, -np.inf, np.nan, 2.0 ** -54, -2.0 ** -54, 2.0 ** -55, 511.999999, 512.0, -512.0, 1023.999, 1024.0,
+          -1024.0, 709.78, 709.79, -745.13, -745.14, -708.4, 5e-324, -5e-324]
+    x[2 * k:2 * k + len(sp)] = sp
+    d = torch.from_numpy(x).cuda()
+    bad = ctypes.c_int64(-1)
+    N.check(N.lib().fsq_selftest_exp(d.data_ptr(), n, ctypes.byref(bad), torch.cuda.current_stream().cuda_stream), "selftest")
+    assert bad.value == 0
