@@ -96,41 +96,61 @@ __global__ void k6_cross_power2(const cplx* __restrict__ F, const cplx* __restri
 __device__ __forceinline__ double fftfreq_idx(int i, int n) { return (double)((i + n / 2) % n) - floor(n / 2.0); }  // ifftshift(arange(n)) - floor(n/2)
 
 // _dftups (phase_correlate.py:137-196): out[u][v] = sum_r sum_c rk[u][r] * data[r][c] * ck[c][v].
-// grid = (up, pairs); block = 256.  T[u][c] is staged in LDS.
+// grid = (up, pairs); block = 256; dynamic LDS = (rows + cols) complex.
+//   stage 1: the row kernel rk[u][.] of this block's u is evaluated ONCE into LDS (rows sincos instead of rows x cols),
+//            then T[c] = sum_r rk[u][r] * data[r][c], thread per column, r in order (coalesced reads of data);
+//   stage 2: out[u][v] = sum_c T[c] * ck[c][v]: every thread takes the columns c = tid, tid + 256, ..., the partial sums
+//            are combined by a fixed-shape tree (wave shuffles, then the 4 waves in order) - deterministic.
 __global__ void __launch_bounds__(256) k6_dftups(const cplx* __restrict__ data, int rows, int cols, int up, int uf,
                                                  const double* __restrict__ offs /*[pairs][2] row_off, col_off*/,
                                                  cplx* __restrict__ out /*[pairs][up][up]*/)
 {
-    extern __shared__ cplx T[];                       // [cols]
-    const int u = blockIdx.x, pair = blockIdx.y;
+    extern __shared__ cplx lds_c[];
+    cplx* Wr = lds_c;                                 // [rows]
+    cplx* T = lds_c + rows;                           // [cols]
+    __shared__ cplx wsum[4];
+    const int u = blockIdx.x, pair = blockIdx.y, tid = threadIdx.x;
     const cplx* d = data + (size_t)pair * rows * cols;
     const double roff = offs[2 * pair], coff = offs[2 * pair + 1];
     const double cr = -2.0 * 3.141592653589793 / ((double)rows * uf), cc = -2.0 * 3.141592653589793 / ((double)cols * uf);
-    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+    for (int r = tid; r < rows; r += blockDim.x) {
+        double ph = cr * (((double)u - roff) * fftfreq_idx(r, rows));
+        double s, co;
+        sincos(ph, &s, &co);
+        Wr[r] = make_double2(co, s);
+    }
+    __syncthreads();
+    for (int c = tid; c < cols; c += blockDim.x) {
         cplx acc = make_double2(0., 0.);
         for (int r = 0; r < rows; r++) {
-            double ph = cr * (((double)u - roff) * fftfreq_idx(r, rows));
-            double s, co;
-            sincos(ph, &s, &co);
-            cplx w = make_double2(co, s);
-            cplx v = d[(size_t)r * cols + c];
+            const cplx w = Wr[r];
+            const cplx v = d[(size_t)r * cols + c];
             acc.x += w.x * v.x - w.y * v.y;
             acc.y += w.x * v.y + w.y * v.x;
         }
         T[c] = acc;
     }
     __syncthreads();
-    for (int v = threadIdx.x; v < up; v += blockDim.x) {
+    for (int v = 0; v < up; v++) {
         cplx acc = make_double2(0., 0.);
-        for (int c = 0; c < cols; c++) {
+        for (int c = tid; c < cols; c += blockDim.x) {
             double ph = cc * (fftfreq_idx(c, cols) * ((double)v - coff));
             double s, co;
             sincos(ph, &s, &co);
-            cplx t = T[c];
+            const cplx t = T[c];
             acc.x += t.x * co - t.y * s;
             acc.y += t.x * s + t.y * co;
         }
-        out[((size_t)pair * up + u) * up + v] = acc;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o); }
+        if ((tid & 63) == 0) wsum[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            cplx t = wsum[0];
+            for (int k = 1; k < 4; k++) { t.x += wsum[k].x; t.y += wsum[k].y; }
+            out[((size_t)pair * up + u) * up + v] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -226,7 +246,7 @@ extern "C" int fsq_phase_correlate(const double* d_ref, const double* d_reg, int
         }
         CK(hipMemcpyAsync(offs, hoff.data(), 2 * n_pairs * sizeof(double), hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k6_cross_power2, dim3((unsigned)((ntot + 255) / 256)), dim3(256), 0, s, F, G, P, ntot);
-        hipLaunchKernelGGL(k6_dftups, dim3(up, n_pairs), dim3(256), (size_t)W * sizeof(cplx), s, P, H, W, up, uf, offs, U);
+        hipLaunchKernelGGL(k6_dftups, dim3(up, n_pairs), dim3(256), (size_t)(H + W) * sizeof(cplx), s, P, H, W, up, uf, offs, U);
         const double norm = mid_row * mid_col * (double)uf * uf;
         hipLaunchKernelGGL(k6_argmax, dim3(n_pairs), dim3(256), 0, s, U, (size_t)up * up, 1.0 / norm, 1, peaks);
         CK(hipMemcpyAsync(hp2.data(), peaks, n_pairs * sizeof(Peak), hipMemcpyDeviceToHost, s));
