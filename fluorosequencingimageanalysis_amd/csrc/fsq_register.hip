@@ -10,6 +10,7 @@
 // reductions) or small dense complex sums (the upsampled DFT), everything in fp64 like the reference.
 #include <hipfft/hipfft.h>
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -154,6 +155,98 @@ __global__ void __launch_bounds__(256) k6_dftups(const cplx* __restrict__ data, 
     }
 }
 
+// ---- the same product on the matrix cores -------------------------------------------------------------------------
+// T[u][c] = sum_r rk[u][r] * data[r][c] is a (up x rows) x (rows x cols) complex GEMM - the one dense contraction of
+// the whole path - so it runs on v_mfma_f64_16x16x4_f64 (fp64 in, fp64 accumulate: same precision as the reference's
+// numpy.dot): k6_rowkernel writes rk transposed and zero-padded to a multiple of 16 rows, rkT[r][u]; one wave of
+// k6_dft_mfma owns a 32 x 16 block of T (2 M-tiles, real and imaginary accumulators = 16 doubles per lane) and walks
+// r in steps of 4, each step being 8 MFMAs fed by three 16-byte loads per lane (A: rkT[r0 + l/16][16 mt + l%16],
+// B: data[r0 + l/16][c0 + l%16]; C/D: column l%16, row l/16 + 4 reg).  k6_dft_cols then applies the column kernel.
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) k6_rowkernel(int rows, int up, int Mp, int uf, const double* __restrict__ offs,
+                                                    cplx* __restrict__ rkT /*[pairs][rows][Mp]*/)
+{
+    const int pair = blockIdx.y;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)rows * Mp) return;
+    const int r = (int)(i / Mp), u = (int)(i - (long long)r * Mp);
+    cplx w = make_double2(0., 0.);
+    if (u < up) {
+        const double cr = -2.0 * 3.141592653589793 / ((double)rows * uf);
+        double ph = cr * (((double)u - offs[2 * pair]) * fftfreq_idx(r, rows));
+        double s, co;
+        sincos(ph, &s, &co);
+        w = make_double2(co, s);
+    }
+    rkT[((size_t)pair * rows + r) * Mp + u] = w;
+}
+
+// grid = (cols / 16, Mp / 32 rounded up, pairs), block = 64
+__global__ void __launch_bounds__(64) k6_dft_mfma(const cplx* __restrict__ data, const cplx* __restrict__ rkT, int rows, int cols,
+                                                  int Mp, cplx* __restrict__ T /*[pairs][Mp][cols]*/)
+{
+    const int lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
+    const int c0 = blockIdx.x * 16, m0 = blockIdx.y * 32, pair = blockIdx.z;
+    const bool two = (m0 + 16) < Mp;                       // Mp is a multiple of 16: the last block may hold one M-tile
+    const cplx* d = data + (size_t)pair * rows * cols + c0 + li;
+    const cplx* a = rkT + (size_t)pair * rows * Mp + m0 + li;
+    v4f64 re0 = {0., 0., 0., 0.}, im0 = re0, re1 = re0, im1 = re0;
+    for (int r0 = 0; r0 < rows; r0 += 4) {
+        const int r = r0 + lk;
+        const cplx b = d[(size_t)r * cols];
+        const cplx a0 = a[(size_t)r * Mp];
+        const cplx a1 = two ? a[(size_t)r * Mp + 16] : make_double2(0., 0.);
+        re0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b.x, re0, 0, 0, 0);
+        re0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0.y, b.y, re0, 0, 0, 0);
+        im0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b.y, im0, 0, 0, 0);
+        im0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b.x, im0, 0, 0, 0);
+        re1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b.x, re1, 0, 0, 0);
+        re1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1.y, b.y, re1, 0, 0, 0);
+        im1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b.y, im1, 0, 0, 0);
+        im1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b.x, im1, 0, 0, 0);
+    }
+    cplx* t = T + (size_t)pair * Mp * cols + c0 + li;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int u = m0 + lk + 4 * g;
+        t[(size_t)u * cols] = make_double2(re0[g], im0[g]);
+        if (two) t[(size_t)(u + 16) * cols] = make_double2(re1[g], im1[g]);
+    }
+}
+
+// out[u][v] = sum_c T[u][c] * ck[c][v]; grid = (up, pairs), block = 256 (same reduction tree as k6_dftups' stage 2)
+__global__ void __launch_bounds__(256) k6_dft_cols(const cplx* __restrict__ T, int cols, int Mp, int up, int uf,
+                                                   const double* __restrict__ offs, cplx* __restrict__ out)
+{
+    __shared__ cplx wsum[4];
+    const int u = blockIdx.x, pair = blockIdx.y, tid = threadIdx.x;
+    const cplx* t = T + ((size_t)pair * Mp + u) * cols;
+    const double coff = offs[2 * pair + 1];
+    const double cc = -2.0 * 3.141592653589793 / ((double)cols * uf);
+    for (int v = 0; v < up; v++) {
+        cplx acc = make_double2(0., 0.);
+        for (int c = tid; c < cols; c += blockDim.x) {
+            double ph = cc * (fftfreq_idx(c, cols) * ((double)v - coff));
+            double s, co;
+            sincos(ph, &s, &co);
+            const cplx x = t[c];
+            acc.x += x.x * co - x.y * s;
+            acc.y += x.x * s + x.y * co;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { acc.x += __shfl_xor(acc.x, o); acc.y += __shfl_xor(acc.y, o); }
+        if ((tid & 63) == 0) wsum[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            cplx x = wsum[0];
+            for (int k = 1; k < 4; k++) { x.x += wsum[k].x; x.y += wsum[k].y; }
+            out[((size_t)pair * up + u) * up + v] = x;
+        }
+        __syncthreads();
+    }
+}
+
 struct PlanKey {
     int H, W, batch, dev;
     bool operator<(const PlanKey& o) const { return std::tie(H, W, batch, dev) < std::tie(o.H, o.W, o.batch, o.dev); }
@@ -246,7 +339,18 @@ extern "C" int fsq_phase_correlate(const double* d_ref, const double* d_reg, int
         }
         CK(hipMemcpyAsync(offs, hoff.data(), 2 * n_pairs * sizeof(double), hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k6_cross_power2, dim3((unsigned)((ntot + 255) / 256)), dim3(256), 0, s, F, G, P, ntot);
-        hipLaunchKernelGGL(k6_dftups, dim3(up, n_pairs), dim3(256), (size_t)(H + W) * sizeof(cplx), s, P, H, W, up, uf, offs, U);
+        const int Mp = 16 * ((up + 15) / 16);
+        if ((W % 16) == 0 && (H % 4) == 0 && Mp <= W && Mp <= H && !getenv("FSQ_REGISTER_NO_MFMA")) {
+            // matrix-core path; F and G are free by now and each pair's slot holds rows x Mp resp. Mp x cols elements
+            cplx* rkT = F;
+            cplx* Tm = G;
+            hipLaunchKernelGGL(k6_rowkernel, dim3((unsigned)(((size_t)H * Mp + 255) / 256), n_pairs), dim3(256), 0, s, H, up, Mp, uf, offs, rkT);
+            // (pair slots of rkT / T are packed back to back: H*Mp and Mp*W elements per pair, both <= H*W)
+            hipLaunchKernelGGL(k6_dft_mfma, dim3(W / 16, (Mp + 31) / 32, n_pairs), dim3(64), 0, s, P, rkT, H, W, Mp, Tm);
+            hipLaunchKernelGGL(k6_dft_cols, dim3(up, n_pairs), dim3(256), 0, s, Tm, W, Mp, up, uf, offs, U);
+        } else {
+            hipLaunchKernelGGL(k6_dftups, dim3(up, n_pairs), dim3(256), (size_t)(H + W) * sizeof(cplx), s, P, H, W, up, uf, offs, U);
+        }
         const double norm = mid_row * mid_col * (double)uf * uf;
         hipLaunchKernelGGL(k6_argmax, dim3(n_pairs), dim3(256), 0, s, U, (size_t)up * up, 1.0 / norm, 1, peaks);
         CK(hipMemcpyAsync(hp2.data(), peaks, n_pairs * sizeof(Peak), hipMemcpyDeviceToHost, s));
