@@ -6,8 +6,9 @@
 //   (row_max, col_max) = argmax(cc)                     lexicographic (real, imag) like numpy, first hit
 //   upsample_factor > 1: matrix-multiply DFT of G*conj(F) on a ceil(1.5*uf)^2 grid around the peak,
 //                        argmax again, error / diffphase from the peak value       (:94-122)
-// All spectra stay in HBM (3 x 16 B/px per pair); the kernels are HBM-streaming (cross-power,
-// reductions) or small dense complex sums (the upsampled DFT), everything in fp64 like the reference.
+// All spectra stay in HBM (3 x 16 B/px per pair); the kernels are HBM-streaming (cross-power, reductions) except
+// the upsampled DFT, whose row product is a complex GEMM on v_mfma_f64_16x16x4_f64 (k6_dft_mfma below);
+// everything in fp64 like the reference.
 #include <hipfft/hipfft.h>
 
 #include <cstdlib>
