@@ -134,3 +134,35 @@ def test_lane_pipeline_equals_single_engine(env):
         for f in range(6):      # only [offsets[f], offsets[f] + nkeep[f]) of a field's slice of `keep` is defined
             g = 6 * k + f
             assert np.array_equal(kk[off[f]:off[f] + nk[f]] + base[k], ref_keep[roff[g]:roff[g] + ref_nk[g]])
+
+
+def test_fuzz_small_fields_vs_oracle(env):
+    """Random small fields (odd shapes, sparse to crowded, dim to saturated, varying noise) and random detection /
+    consolidation parameters: the full find_peptides table equals the oracle's, bit for bit, for every one of them."""
+    torch, N, engine, pflib, pc, synth, O = env
+    rng = np.random.default_rng(2024)
+    for t in range(40):
+        H, W = int(rng.integers(24, 150)), int(rng.integers(24, 150))
+        img = synth.make_field(10_000 + t, (H, W), int(rng.integers(0, max(2, H * W // 400))))
+        mode = t % 5
+        if mode == 1:                                   # saturate part of the frame
+            img = np.minimum(img.astype(np.int64) * int(rng.integers(5, 40)), 65535).astype(np.uint16)
+        elif mode == 2:                                 # dim: counts of a few units
+            img = (img // 40).astype(np.uint16)
+        elif mode == 3:                                 # pure noise
+            img = rng.integers(0, int(rng.integers(2, 5000)), (H, W)).astype(np.uint16)
+        med = int(rng.choice([3, 5, 7]))
+        c_std = float(rng.choice([1.0, 2.0, 3.5]))
+        r2 = float(rng.choice([0.3, 0.7, 0.9]))
+        rad = int(rng.choice([2, 4, 7]))
+        try:
+            rows, fits, keep, key = O.find_peptides(img, med_size=med, c_std=c_std, r2_thr=r2, radius=rad, n_threads=16)
+            exp_err = None
+        except AssertionError as e:                     # the reference's re-key assert (pflib.py:518)
+            exp_err = e
+        if exp_err is not None:
+            with pytest.raises(AssertionError):
+                pflib.find_peptides(img, median_filter_size=med, c_std=c_std, r_2_threshold=r2, consolidation_radius=rad)
+            continue
+        got = pflib.find_peptides(img, median_filter_size=med, c_std=c_std, r_2_threshold=r2, consolidation_radius=rad)
+        _same_table(got, rows, fits, keep, key)
