@@ -76,6 +76,7 @@ struct Ctx {
     FitStat* stat;            // [n]
     long long cap;            // queue capacity (positions)
     int* slow_total;          // statistics: fits that went through the plain-division kernel
+    int wave_prio;            // late rounds: raise the waves' issue priority (they share CUs with another lane's big kernels)
     int force_redo;           // debug: take qrfac's norm re-computation branch at every step (FSQ_DEBUG_FORCE_NORM_RECOMPUTE)
     int force_slow_mod;       // debug: route every fit with idx % mod == 0 through the plain-division kernel
 };
@@ -221,6 +222,7 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
     __shared__ double lds[Q_KA_END * 16];
     const int lane = threadIdx.x, quad = lane >> 2, c4 = lane & 3, qbase = lane & ~3;
     const int n7 = FSQ_NP;
+    if (c.wave_prio) __builtin_amdgcn_s_setprio(3);
     const int cntA = FAST ? *cntA_p : *slow_cnt;
     if (!FAST && blockIdx.x == 0 && threadIdx.x == 0 && cntA > 0) atomicAdd(c.slow_total, cntA);
     if (FAST && blockIdx.x == 0 && threadIdx.x < 4) next_counters[threadIdx.x] = 0;
@@ -623,6 +625,7 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
                                                   double* __restrict__ QC, int* __restrict__ cntC, int lm_first)
 {
     __shared__ double scr[21 * 64];
+    if (c.wave_prio) __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x;
     const int cntB = *cntB_p;
     double* myscr = scr + lane;
@@ -1110,6 +1113,7 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     int h_init[12] = {(int)n, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     c.slow_total = ctl + 8;
+    c.wave_prio = 0;
     FSQ_HIP_CHECK(hipMemcpyAsync(ctl, h_init, sizeof(h_init), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(kinit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c, QA[0]);
     const bool ref = (mode == FSQ_MODE_REF);
@@ -1189,6 +1193,7 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
             if (!hi.s && alive < hiprio_below && n >= 4 * hiprio_below) {      // (small batches gain nothing)
                 hi.s = hi_acquire();
                 if (hi.s) s = hi.s;            // the user's stream is idle here: plain hand-over
+                c.wave_prio = getenv("FSQ_NO_WAVE_PRIO") ? 0 : 1;
             }
         }
         if (getenv("FSQ_DEBUG_MAX_ROUNDS") && round + 1 >= atoi(getenv("FSQ_DEBUG_MAX_ROUNDS"))) {
