@@ -6,8 +6,9 @@
 Workload (BASELINE.json configs[1]): 1 024 synthetic 512x512 uint16 fields per GPU, ~500 spots each
 (seeds rank*1024 .. +1023 of fluorosequencingimageanalysis_amd.synth), resident in HBM before the timed
 region.  One step = detect -> LM-fit every candidate -> R^2 filter + consolidation over the whole batch
-(+ the RCCL gather of the peak tables to rank 0 when N > 1).  value = candidate LM solves per second,
-whole job.  Prints ONE JSON line on rank 0.
+(+ the RCCL gather of the peak tables to rank 0 when N > 1).  The K timed steps are K batches streamed through
+engine.StreamPipeline (continuous batching of the LM fits; --pipeline lanes runs every step stand-alone).
+value = candidate LM solves per second, whole job.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -66,11 +67,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--fields", type=int, default=1024, help="fields per GPU")
+    ap.add_argument("--fields", type=int, default=1024, help="fields per GPU and step")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--spots", type=int, default=500)
-    ap.add_argument("--lanes", type=int, default=2, help="shares of the batch worked side by side on their own streams")
+    ap.add_argument("--pipeline", choices=("stream", "lanes"), default="stream",
+                    help="stream: continuous batching of the LM fits across steps (engine.StreamPipeline); "
+                         "lanes: every step a stand-alone batch, worked as --lanes shares (engine.LanePipeline)")
+    ap.add_argument("--lanes", type=int, default=2, help="lanes pipeline: shares of the batch worked side by side")
+    ap.add_argument("--depth", type=int, default=16, help="stream pipeline: batches in flight at most")
+    ap.add_argument("--inject-below", type=int, default=None, help="stream pipeline: submit the next batch once fewer fits are alive")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the H2D-inclusive and dict-materialising side measurements")
     a = ap.parse_args()
 
     import torch
@@ -95,10 +102,127 @@ def main():
     d_img = E.to_device_u16(imgs, dev)
     prm = E.detect_params(5, pflib.default_correlation_matrix, 2)
 
-    # The batch is worked by `lanes` engines on their own HIP streams, lane k owning the k-th contiguous share of
-    # the fields and starting half a pass after lane k-1, so that the latency-bound tail of one share's LM rounds
-    # overlaps the busy early rounds of the other (engine.LanePipeline).  One step = every lane passes once over its
-    # share = one pass over the whole batch.  --lanes 1 runs the batch as a single share.
+    if a.pipeline == "stream":
+        res = run_stream(a, torch, dist, D, E, N, d_img, imgs, prm, dev, rank, world)
+    else:
+        res = run_lanes(a, torch, dist, D, E, N, d_img, prm, dev, rank, world)
+    dt, total, kept, busy_ms, fit_launches, how, cand_tables = res
+
+    tt = torch.tensor([dt, float(total), float(kept)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, total_all, kept_all = float(tmax[0]), float(tsum[1]), float(tsum[2])
+    else:
+        total_all, kept_all = float(total), float(kept)
+    if rank == 0:
+        fits_per_s = total_all * a.steps / dt
+        # the rate the chip sustains on the LM-fit kernels: the fits of all steps over the time those kernels had the
+        # stream (stream pipeline: the fit queue's own stream, busy from the first to the last round of the timed
+        # region; lanes: the time at least one lane's fit launch was running)
+        achieved = total * a.steps * FLOP_PER_FIT / (busy_ms * 1e-3) / 1e12
+        prof = {}
+        ppath = os.path.join(ROOT, "profiles", "fit_counters_latest.json")
+        if os.path.exists(ppath):
+            prof = json.load(open(ppath))
+        traffic = prof.get("fit_kernel_hbm_bytes_per_1024_field_step")
+        if traffic is not None:
+            traffic = traffic * (a.fields / 1024.0)
+        out = {
+            "metric": "psf_lm_fits_per_sec", "value": fits_per_s, "unit": "fits/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1]: %d synthetic %dx%d uint16 fields per GPU, %d spots each, "
+                                   "detect + LM-fit every candidate + consolidate (reference-faithful fp64); %s"
+                                   % (a.fields, a.size, a.size, a.spots, how),
+                       "fields_per_gpu": a.fields, "candidates_per_gpu": int(total),
+                       "parallelism": "fields sharded over %d rank(s), RCCL p2p gather of peak tables" % world},
+            "fields_per_sec": a.fields * world * a.steps / dt,
+            "peaks_per_sec": kept_all * a.steps / dt,
+            "roofline": {"bound": "valu-fp64",
+                         "note": "the LM solve is fp64 vector-ALU work with 98 B of algorithmic I/O per fit: there is no "
+                                 "MFMA-shaped contraction and it is not HBM-bound (see the hbm entry), so it is priced against "
+                                 "the fp64 VECTOR peak - DESIGN.md 4.2",
+                         "kernel": "LM fit = kinit + rounds of (kA_jacobian, kB_step) + kfinish, timed as one unit",
+                         "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
+                         "fits_per_step": int(total), "busy_ms": busy_ms, "busy_ms_per_step": busy_ms / a.steps,
+                         "launches": fit_launches, "flop_per_fit": FLOP_PER_FIT,
+                         "valu_issue_frac": prof.get("valu_issue_frac"), "executed_valu_per_fit": prof.get("executed_valu_per_fit"),
+                         "counters_source": prof.get("source"),
+                         "hbm": {"algorithmic_bytes_per_fit": 98,
+                                 "algorithmic_GBps": 98.0 * total * a.steps / (busy_ms * 1e-3) / 1e9,
+                                 "traffic_GBps": (traffic * a.steps / (busy_ms * 1e-3) / 1e9) if traffic else None,
+                                 "peak_GBps": PEAK_HBM_GBS}},
+        }
+        if not a.no_extras and world == 1:
+            out["extras"] = extras(a, torch, E, N, pflib, imgs, d_img, prm, dev)
+        if not a.no_cpu_baseline:
+            cand, counts, offsets = cand_tables()
+            n_thr = min(16, len(os.sched_getaffinity(0)))     # the box's CPU share for one GPU
+            out["cpu_baseline"] = cpu_baseline(imgs, cand, counts, offsets, n_thr)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _barrier(torch, dist, world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def run_stream(a, torch, dist, D, E, N, d_img, imgs, prm, dev, rank, world):
+    """K steps = K batches streamed through engine.StreamPipeline (continuous batching of the LM fits): a step's
+    detection, its fits and its consolidation all happen inside the timed region, but the slow fits of one step finish
+    inside the round launches of the following steps instead of in hundreds of nearly empty launches of their own."""
+    pipe = E.StreamPipeline(a.fields, a.size, a.size, depth=a.depth, inject_below=a.inject_below, device=dev)
+    sharded = D.ShardedTables(dev) if world > 1 else None
+    kept = [0]
+
+    def on_done(j, eng, total):
+        if sharded is not None:         # the one exchange of the path: this step's peak table to rank 0, in step order
+            sharded.push(j, eng, total)
+        kept[0] = eng.nkeep[eng.n_fields]       # (device scalar; read after the run)
+
+    def steps(n):
+        totals = pipe.run([(d_img, prm)] * n, on_done)
+        if sharded is not None:
+            sharded.flush()
+        return totals
+
+    steps(1)                            # page everything in
+    steps(a.warmup)
+    _barrier(torch, dist, world)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    r0 = pipe.queue.rounds
+    ev0.record(pipe.queue.stream)
+    t0 = time.perf_counter()
+    totals = steps(a.steps)
+    ev1.record(pipe.queue.stream)
+    _barrier(torch, dist, world)
+    dt = time.perf_counter() - t0
+    busy_ms = ev0.elapsed_time(ev1)
+    rounds = pipe.queue.rounds - r0
+    how = ("the steps are streamed through one fit queue (continuous batching, at most %d batches in flight, next batch "
+           "submitted below %d live fits; %d rounds for %d steps)" % (pipe.depth, pipe.inject_below, rounds, a.steps))
+    eng0 = pipe.engines[0]
+
+    def cand_tables():
+        with torch.cuda.stream(pipe.side):
+            t = eng0.detect(d_img, prm)
+            return eng0.candidates(t)
+    return dt, totals[0], int(kept[0]), busy_ms, {"rounds": int(rounds), "steps": a.steps}, how, cand_tables
+
+
+def run_lanes(a, torch, dist, D, E, N, d_img, prm, dev, rank, world):
+    """Every step a stand-alone batch, worked by `lanes` engines on their own HIP streams / host threads, lane k owning
+    the k-th contiguous share of the fields and starting half a pass after lane k-1 (engine.LanePipeline).  Kept for A/B."""
+    assert world == 1, "--pipeline lanes is a single-GPU A/B path"
     lanes = max(1, min(a.lanes, a.fields))
     cut = [a.fields * k // lanes for k in range(lanes + 1)]
     engs = [E.Engine(cut[k + 1] - cut[k], a.size, a.size, device=dev) for k in range(lanes)]
@@ -108,8 +232,6 @@ def main():
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
           for _ in range(lanes)]
     totals = [[0] * max(a.steps, a.warmup, 1) for _ in range(lanes)]
-    import queue
-    outbox = queue.Queue()
 
     def work(timed):
         def f(k, i, eng):
@@ -121,72 +243,22 @@ def main():
                 ev[k][i][1].record()
             eng.consolidate(0.7, 4, True)
             totals[k][i] = total
-            if world > 1:        # the one exchange of the path: this share's peak table, handed to the main thread
-                nk = eng.nkeep.cpu().numpy()
-                offs = eng.offsets.cpu().numpy()
-                idx = np.concatenate([np.arange(offs[f_], offs[f_] + max(int(nk[f_]), 0)) for f_ in range(eng.n_fields)])
-                kept = eng.rows[:total].index_select(0, eng.keep[:total].index_select(0, torch.from_numpy(idx).to(dev)).long())
-                done = torch.cuda.Event()
-                done.record()
-                outbox.put((k, i, kept, done))
         return f
 
-    def gather_all(n_steps):
-        """Main thread: RCCL gather of every (lane, step) table to rank 0, in an order all ranks share."""
-        pending = {}
-        for i in range(n_steps):
-            for k in range(lanes):
-                while (k, i) not in pending:
-                    kk, ii, kept, done = outbox.get()
-                    pending[(kk, ii)] = (kept, done)
-                kept, done = pending.pop((k, i))
-                torch.cuda.current_stream().wait_event(done)
-                kept.record_stream(torch.cuda.current_stream())
-                D.gather_tables(kept, 0)
-
-    def run_steps(n_steps, timed, stagger):
-        if n_steps <= 0:
-            return
-        if world > 1:
-            import threading
-            th = threading.Thread(target=pipe.run, args=(work(timed), n_steps, stagger), daemon=True)
-            th.start()
-            gather_all(n_steps)
-            th.join()
-        else:
-            pipe.run(work(timed), n_steps, stagger)
-
-    # one untimed pass to page everything in and to learn the stagger (half a pass of one share)
     t = time.perf_counter()
-    run_steps(1, False, 0.0)
+    pipe.run(work(False), 1, 0.0)
     torch.cuda.synchronize()
     stagger = 0.5 * (time.perf_counter() - t) if lanes > 1 else 0.0
-    run_steps(a.warmup, False, stagger)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    if a.warmup > 0:
+        pipe.run(work(False), a.warmup, stagger)
+    _barrier(torch, dist, world)
     base_ev.record()
     t0 = time.perf_counter()
-    run_steps(a.steps, True, stagger)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    pipe.run(work(True), a.steps, stagger)
+    _barrier(torch, dist, world)
     dt = time.perf_counter() - t0
     total = sum(totals[k][0] for k in range(lanes))
-    tt = torch.tensor([dt, float(total)], dtype=torch.float64, device=dev)
-    if world > 1:
-        tmax = tt.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = tt.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt, total_all = float(tmax[0]), float(tsum[1])
-    else:
-        total_all = float(total)
-    # LM-fit launches of the timed region: per-launch durations and the time during which at least one was running
     spans = sorted((base_ev.elapsed_time(ev[k][i][0]), base_ev.elapsed_time(ev[k][i][1])) for k in range(lanes) for i in range(a.steps))
-    fit_ms = [e - b_ for b_, e in spans]
     busy_ms, cur_b, cur_e = 0.0, None, None
     for b_, e in spans:
         if cur_e is None or b_ > cur_e:
@@ -195,54 +267,47 @@ def main():
         else:
             cur_e = max(cur_e, e)
     busy_ms += (cur_e - cur_b) if cur_e is not None else 0.0
-    if rank == 0:
-        fit_avg_ms = float(np.mean(fit_ms))
-        fits_per_s = total_all * a.steps / dt
-        # `lanes` launches run side by side, each on a share of the CUs: the rate the chip sustains on this kernel is
-        # the fits of all launches over the time at least one launch was running (= flops per launch / its duration
-        # when lanes == 1)
-        achieved = total * a.steps * FLOP_PER_FIT / (busy_ms * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            # measured for one pass over the 1 024-field batch (rocprofv3 --pmc, tools/collect_profiles.sh); a launch
-            # covers one lane's share of it
-            traffic = json.load(open(tpath)).get("fit_kernel_hbm_bytes_per_1024_field_pass")
-            if traffic is not None:
-                traffic = traffic * (a.fields / 1024.0) / lanes
-        out = {
-            "metric": "psf_lm_fits_per_sec", "value": fits_per_s, "unit": "fits/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d synthetic %dx%d uint16 fields per GPU, %d spots each, "
-                                   "detect + LM-fit every candidate + consolidate (reference-faithful fp64); the batch is worked as %d "
-                                   "share(s) on their own HIP streams"
-                                   % (a.fields, a.size, a.size, a.spots, lanes),
-                       "fields_per_gpu": a.fields, "candidates_per_gpu": int(total),
-                       "parallelism": "fields sharded over %d rank(s), RCCL p2p gather of peak tables" % world},
-            "fields_per_sec": a.fields * world * a.steps / dt,
-            "roofline": {"bound": "valu-fp64",
-                         "note": "the LM solve is fp64 vector-ALU work with 98 B of algorithmic I/O per fit: there is no "
-                                 "MFMA-shaped contraction and it is not HBM-bound (see the hbm entry), so it is priced against "
-                                 "the fp64 VECTOR peak - DESIGN.md 4.2",
-                         "kernel": "LM fit = kinit + rounds of (kA_jacobian, kB_step) + kfinish, timed as one unit",
-                         "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
-                         "launch_ms": fit_avg_ms, "fits_per_launch": int(total // lanes), "concurrent_launches": lanes,
-                         "launches": lanes * a.steps, "busy_ms": busy_ms, "flop_per_fit": FLOP_PER_FIT,
-                         "hbm": {"algorithmic_bytes_per_fit": 98,
-                                 "algorithmic_GBps": 98.0 * total * a.steps / (busy_ms * 1e-3) / 1e9,
-                                 "traffic_GBps": (traffic * lanes * a.steps / (busy_ms * 1e-3) / 1e9) if traffic else None,
-                                 "peak_GBps": PEAK_HBM_GBS}},
-        }
-        if not a.no_cpu_baseline:
-            cand, counts, offsets = engs[0].candidates(totals[0][0])
-            n_thr = min(16, len(os.sched_getaffinity(0)))     # the box's CPU share for one GPU
-            out["cpu_baseline"] = cpu_baseline(imgs, cand, counts, offsets, n_thr)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    kept = sum(int(e.nkeep[e.n_fields]) for e in engs)
+    how = "every step a stand-alone batch worked as %d share(s) on their own HIP streams" % lanes
+    return (dt, total, kept, busy_ms, {"fit_calls": lanes * a.steps}, how,
+            lambda: engs[0].candidates(totals[0][0]))
+
+
+def extras(a, torch, E, N, pflib, imgs, d_img, prm, dev):
+    """Side measurements SURVEY 8d lists next to the headline: the same stream pipeline with every step's images
+    uploaded from pinned host memory inside the timed region, and the rate of the dict-materialising pflib surface."""
+    out = {}
+    n = min(a.steps, 6)
+    pinned = torch.from_numpy(imgs.view(np.int16)).pin_memory()
+    bufs = [torch.empty_like(d_img) for _ in range(3)]
+    pipe = E.StreamPipeline(a.fields, a.size, a.size, depth=a.depth, inject_below=a.inject_below, device=dev)
+
+    def jobs(k):
+        for j in range(k):
+            b = bufs[j % 3]
+            torch.cuda.current_stream().wait_stream(pipe.queue.stream)   # kinit of the batch that used this buffer
+            b.copy_(pinned, non_blocking=True)
+            yield b, prm
+
+    pipe.run(jobs(1))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pipe.run(jobs(n))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pipe.close()
+    out["h2d_inclusive_fields_per_sec"] = a.fields * n / dt
+    out["h2d_inclusive_note"] = "%d steps, each step's %d fields copied from pinned host memory (%.0f MiB) on the side stream" % (
+        n, a.fields, imgs.nbytes / 2**20)
+    m = min(64, a.fields)
+    pflib.find_peptides_batch(imgs[:2])
+    t0 = time.perf_counter()
+    d = pflib.find_peptides_batch(imgs[:m])
+    dt = time.perf_counter() - t0
+    out["find_peptides_batch_fields_per_sec"] = m / dt
+    out["find_peptides_batch_note"] = ("pflib.find_peptides_batch on %d host fields -> list of dicts of 12-tuples "
+                                       "(H2D + one stand-alone GPU pass + D2H + Python tuples; %d peaks)" % (m, sum(len(x) for x in d)))
+    return out
 
 
 if __name__ == "__main__":

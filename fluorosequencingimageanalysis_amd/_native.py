@@ -10,7 +10,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FSQ_HIP_LIB") or os.path.join(HERE, "csrc", "libfsq_hip.so")   # env: A/B builds
 
-FSQ_OK, FSQ_EINVAL, FSQ_ENOMEM, FSQ_ERANGE, FSQ_EHIP, FSQ_EASSERT, FSQ_ENOTIMPL = 0, -1, -2, -3, -4, -5, -6
+FSQ_OK, FSQ_EINVAL, FSQ_ENOMEM, FSQ_ERANGE, FSQ_EHIP, FSQ_EASSERT, FSQ_ENOTIMPL, FSQ_EAGAIN = 0, -1, -2, -3, -4, -5, -6, -7
+MAX_TICKETS = 32
 MODE_REF, MODE_TEXTBOOK, ENGINE_LANE, ENGINE_QUAD = 0, 1, 0x100, 0x200
 
 ROW_DTYPE = np.dtype([(k, np.float64) for k in
@@ -42,12 +43,25 @@ _SIGS = {
     "fsq_fit_candidates": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                           ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                           ctypes.c_void_p]),
+    "fsq_fitq_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int64]),
+    "fsq_fitq_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                       ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "fsq_fitq_submit": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),
+    "fsq_fitq_advance": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64),
+                                        ctypes.POINTER(ctypes.c_int)]),
+    "fsq_fitq_take": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "fsq_fitq_alive": (ctypes.c_int64, [ctypes.c_void_p]),
+    "fsq_fitq_rounds": (ctypes.c_int64, [ctypes.c_void_p]),
+    "fsq_fitq_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "fsq_fit_rois": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_int64, ctypes.c_void_p]),
     "fsq_consolidate_workspace_bytes": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "fsq_consolidate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+    "fsq_kept_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                     ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
     "fsq_fit_images": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                       ctypes.c_void_p]),
     "fsq_phase_correlate": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -91,6 +105,8 @@ def check(rc, what):
         raise NotImplementedError(what)
     if rc == FSQ_ENOMEM:
         raise MemoryError(what)
+    if rc == FSQ_EAGAIN:
+        raise BlockingIOError("%s: the fit queue has no room right now" % what)
     if rc == FSQ_EHIP:
         raise RuntimeError("%s: HIP error: %s" % (what, lib().fsq_last_hip_error().decode()))
     raise RuntimeError("%s: error %d" % (what, rc))

@@ -156,7 +156,46 @@ __global__ void k5_total(int* __restrict__ nkeep, int n_fields)
     }
 }
 
+// Kept rows of all fields, contiguous and in field order (the peak table that is gathered / copied to the host).
+// One block per field; the field's position in the output is the sum of the kept counts before it.
+__global__ void __launch_bounds__(256) k5_kept_rows(const FsqRow* __restrict__ rows, const int* __restrict__ keep,
+                                                    const int* __restrict__ offsets, const int* __restrict__ nkeep,
+                                                    FsqRow* __restrict__ out, int* __restrict__ out_offsets, long long cap)
+{
+    __shared__ int s_part[256];
+    const int f = blockIdx.x, t = threadIdx.x;
+    int acc = 0;
+    for (int g = t; g < f; g += 256) acc += nkeep[g] > 0 ? nkeep[g] : 0;
+    s_part[t] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) s_part[t] += s_part[t + w];
+        __syncthreads();
+    }
+    const int base = s_part[0], nk = nkeep[f] > 0 ? nkeep[f] : 0, off = offsets[f];
+    if (t == 0) out_offsets[f] = base;
+    if (t == 0 && f == (int)gridDim.x - 1) out_offsets[f + 1] = base + nk;
+    // a row is 128 bytes = 8 x 16 bytes: 8 consecutive threads move one row
+    const uint4* src = (const uint4*)rows;
+    uint4* dst = (uint4*)out;
+    for (int k = t >> 3; k < nk; k += 32) {
+        if ((long long)base + k >= cap) break;
+        const int r = keep[off + k];
+        dst[((size_t)base + k) * 8 + (t & 7)] = src[(size_t)r * 8 + (t & 7)];
+    }
+}
+
 }  // namespace
+
+extern "C" int fsq_kept_rows(const FsqRow* d_rows, const int32_t* d_keep, const int32_t* d_offsets, const int32_t* d_nkeep,
+                             int n_fields, FsqRow* d_out, int64_t cap, int32_t* d_out_offsets, void* stream)
+{
+    if (n_fields < 1 || !d_rows || !d_keep || !d_offsets || !d_nkeep || (!d_out && cap > 0) || !d_out_offsets || cap < 0) return FSQ_EINVAL;
+    hipLaunchKernelGGL(k5_kept_rows, dim3(n_fields), dim3(256), 0, (hipStream_t)stream, d_rows, d_keep, d_offsets, d_nkeep,
+                       d_out, d_out_offsets, (long long)cap);
+    FSQ_HIP_CHECK(hipGetLastError());
+    return FSQ_OK;
+}
 
 extern "C" int64_t fsq_consolidate_workspace_bytes(int n_fields, int H, int W)
 {

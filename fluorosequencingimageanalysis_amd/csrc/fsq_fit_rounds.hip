@@ -23,6 +23,7 @@
 #include <cstdlib>
 
 #include <mutex>
+#include <new>
 #include <vector>
 
 #include "fsq_common.h"
@@ -68,14 +69,18 @@ struct FitStat {              // by candidate: ROI statistics (kinit)
     double vmax, vmean;
 };
 
+// The by-candidate arrays form a POOL of slots; a batch of candidates (one fsq_fit_* call, or one submission to a
+// FsqFitQueue) owns a contiguous range of slots while it is in flight, and its queue records carry (slot, ticket).
+// The round kernels only ever see slots - fits of several batches share the queues and the launches.
 struct Ctx {
-    const uint16_t* src; const int32_t* cand; int H, W; long long n; int from_image;
-    uint16_t* roi;            // [n][32]: the 25 pixels of every ROI, gathered once by kinit (64 bytes per fit)
-    double* fvec;             // [n][25]
-    FitOut* out;              // [n]
-    FitStat* stat;            // [n]
+    uint16_t* roi;            // [pool][32]: the 25 pixels of every ROI, gathered once by kinit (64 bytes per fit)
+    double* fvec;             // [pool][25]
+    FitOut* out;              // [pool]
+    FitStat* stat;            // [pool]
     long long cap;            // queue capacity (positions)
     int* slow_total;          // statistics: fits that went through the plain-division kernel
+    int* done;                // [FSQ_MAX_TICKETS]: terminated fits per batch in flight
+    int tshift;               // a record's tag = slot | ticket << tshift (one 32-bit word: the kernels are at the register limit)
     int wave_prio;            // late rounds: raise the waves' issue priority (they share CUs with another lane's big kernels)
     int force_redo;           // debug: take qrfac's norm re-computation branch at every step (FSQ_DEBUG_FORCE_NORM_RECOMPUTE)
     int force_slow_mod;       // debug: route every fit with idx % mod == 0 through the plain-division kernel
@@ -95,11 +100,35 @@ FSQ_DEV int wave_reserve(int* counter, bool want)
     return base + __popcll(m & ((1ull << lane) - 1ull));
 }
 
+// One batch of candidates: where its pixels come from, which pool slots it owns, where its rows go.
+struct BatchArgs {
+    const uint16_t* src; const int32_t* cand; int H, W; long long n; int from_image;
+    long long base;           // first pool slot
+    int ticket;
+};
+
+// Count the lanes with `term` set into their batches' done counters: one atomic per wave per batch present.
+FSQ_DEV void wave_mark_done(int* done, bool term, int ticket)
+{
+    unsigned long long m = __ballot(term);
+    const int lane = threadIdx.x & 63;
+    while (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        const int t = __shfl(ticket, leader);
+        const unsigned long long mm = __ballot(term && ticket == t);
+        if (lane == leader) atomicAdd(done + t, __popcll(mm));
+        m &= ~mm;
+    }
+}
+
+FSQ_DEV int tag_slot(const Ctx& c, int tag) { return (int)((unsigned)tag & ((1u << c.tshift) - 1u)); }
+FSQ_DEV int tag_ticket(const Ctx& c, int tag) { return (int)((unsigned)tag >> c.tshift); }
+
 FSQ_DEV int rpk(int i, int k) { return i * 7 - (i * (i - 1)) / 2 + (k - i); }     // index of (i,k), i <= k, in R upper[28]
 FSQ_DEV double pack2(int a, int b) { return __longlong_as_double(((long long)(unsigned)a) | ((long long)b << 32)); }
 FSQ_DEV void unpack2(double v, int* a, int* b) { long long u = __double_as_longlong(v); *a = (int)(unsigned)(u & 0xffffffffll); *b = (int)(u >> 32); }
 
-FSQ_DEV void roi_pixels(const Ctx& c, long long idx, double* d)
+FSQ_DEV void roi_pixels(const BatchArgs& c, long long idx, double* d)
 {
     if (c.from_image) {
         const int f = c.cand[3 * idx], h = c.cand[3 * idx + 1], w = c.cand[3 * idx + 2];
@@ -124,20 +153,24 @@ FSQ_DEV void roi_compact(const Ctx& c, long long idx, double* d)
     for (int k = 0; k < FSQ_NPIX; k++) d[k] = (double)((w[k >> 1] >> (16 * (k & 1))) & 0xffffu);
 }
 
-__global__ void __launch_bounds__(256) kinit(Ctx c, double* __restrict__ QA)
+__global__ void __launch_bounds__(256) kinit(Ctx c, BatchArgs b, double* __restrict__ QA, int* __restrict__ cntA)
 {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c.n) return;
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = i0 < b.n;
+    const long long i = ok ? i0 : 0;            // idle lanes of the last block recompute fit 0 and store nothing
+    const int pos = wave_reserve(cntA, ok);     // appended behind whatever the queue already holds
+    if (b.n <= 0) return;
+    const long long slot = b.base + i;
     double v[FSQ_NPIX];
-    roi_pixels(c, i, v);
-    {
+    roi_pixels(b, i, v);
+    if (ok) {
         unsigned w[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             unsigned lo = (2 * k < FSQ_NPIX) ? (unsigned)v[2 * k] : 0u, hi = (2 * k + 1 < FSQ_NPIX) ? (unsigned)v[2 * k + 1] : 0u;
             w[k] = lo | (hi << 16);
         }
-        uint4* dst = (uint4*)(c.roi + (size_t)i * 32);
+        uint4* dst = (uint4*)(c.roi + (size_t)slot * 32);
         dst[0] = make_uint4(w[0], w[1], w[2], w[3]); dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
         dst[2] = make_uint4(w[8], w[9], w[10], w[11]); dst[3] = make_uint4(w[12], w[13], w[14], w[15]);
     }
@@ -148,14 +181,15 @@ __global__ void __launch_bounds__(256) kinit(Ctx c, double* __restrict__ QA)
     for (int pass = 0; pass < FSQ_NPIX; pass++)          // odd-even transposition sort: median = v[12]
 #pragma unroll
         for (int k = (pass & 1); k + 1 < FSQ_NPIX; k += 2) {
-            double a = v[k], b = v[k + 1];
-            v[k] = a < b ? a : b;
-            v[k + 1] = a < b ? b : a;
+            double a = v[k], b_ = v[k + 1];
+            v[k] = a < b_ ? a : b_;
+            v[k + 1] = a < b_ ? b_ : a;
         }
+    if (!ok) return;
     const double vmedian = v[12], vmean = isum / 25.0;
     const double llim1 = (mx - vmean) / 3.0;                               // pflib.py:207-209
     double x0[FSQ_NP] = {vmedian, mx, 2.5, 2.5, 1., 1., 0.};               // pflib.py:201-202
-    double* q = QA + i;
+    double* q = QA + pos;
     const long long cap = c.cap;
 #pragma unroll
     for (int k = 0; k < FSQ_NP; k++) {                                     // gaussfitter.py:202-204
@@ -165,22 +199,22 @@ __global__ void __launch_bounds__(256) kinit(Ctx c, double* __restrict__ QA)
         q[(A_X + k) * cap] = t;
         q[(A_DIAG + k) * cap] = 0.;
     }
-    q[A_IDX * cap] = pack2((int)i, 0);
+    q[A_IDX * cap] = pack2((int)((unsigned)slot | ((unsigned)b.ticket << c.tshift)), 0);
     q[A_LLIM1 * cap] = llim1; q[A_FNORM * cap] = 0.; q[A_PAR * cap] = 0.; q[A_DELTA * cap] = 0.; q[A_XNORM * cap] = 0.;
     q[A_ITER * cap] = pack2(1, 0);                                         // niter = 1, nfev = 0  (nfev == 0 <=> fresh)
-    c.stat[i].vmax = mx; c.stat[i].vmean = vmean;
+    c.stat[slot].vmax = mx; c.stat[slot].vmean = vmean;
 }
 
 // kA's inputs for one quad, as they sit in registers between the loads and the LDS staging.  The loop of kA is
 // software-pipelined over them: the head (which fit) of the NEXT trip is requested at the top of a trip, the body
 // (that fit's pixels, residuals, x, diag) just before the hand-over stores of the trip, so both memory round trips
 // are hidden behind work instead of opening every trip.
-struct KaHead { int idx, niter, nfev; };
+struct KaHead { int tag, niter, nfev; };
 struct KaBody { uint4 roi; double fv[7], x[2], dg[2], llim1; };
 FSQ_DEV KaHead ka_fetch_head(const double* qa, long long cap)
 {
     KaHead h; int dummy;
-    unpack2(qa[A_IDX * cap], &h.idx, &dummy);
+    unpack2(qa[A_IDX * cap], &h.tag, &dummy);
     unpack2(qa[A_ITER * cap], &h.niter, &h.nfev);
     return h;
 }
@@ -239,7 +273,7 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
         if (base0 + quad < cntA) {
             qpos = base0 + quad;
             hd = ka_fetch_head(QA + qpos, cap);
-            bd = ka_fetch_body(c, QA + qpos, cap, c4, hd.idx);
+            bd = ka_fetch_body(c, QA + qpos, cap, c4, tag_slot(c, hd.tag));
         }
     }
     for (int base = blockIdx.x * 16; base < cntA; base += stride) {
@@ -248,7 +282,7 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
         if (!KA_PIPELINE && active) {           // plain loads at the top of the trip
             qpos = base + quad;
             hd = ka_fetch_head(QA + qpos, cap);
-            bd = ka_fetch_body(c, QA + qpos, cap, c4, hd.idx);
+            bd = ka_fetch_body(c, QA + qpos, cap, c4, tag_slot(c, hd.tag));
         }
         const double* qa = QA + qpos;
         // head of the next trip: requested now, needed only at the end of this one
@@ -261,7 +295,7 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
         }
         bool hz = false, qhz = false;     // FAST: some operand left the range in which fsq_div_by == `/`
         int emin = 0;                     // FAST: smallest exponent among the tracked numerators
-        int idx = 0;
+        int idx = 0, tag = 0;
         double llim1 = 0., fnorm = 0., xnorm = 0., delta = 0., par_in = 0.;
         int niter = 1, nfev = 0;
         bool fresh = false;
@@ -269,7 +303,7 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
         int status = 0;
         double gnorm = 0.;
         if (active) {
-            idx = hd.idx; niter = hd.niter; nfev = hd.nfev;
+            tag = hd.tag; idx = tag_slot(c, tag); niter = hd.niter; nfev = hd.nfev;
             fresh = (nfev == 0);        // llim1 goes to LDS below; fnorm, par, delta, xnorm are fetched when first needed
             {   // lane c4 of the quad converts pixels 8*c4 .. 8*c4+7 of the compact ROI copy
                 const uint4 pw = bd.roi;
@@ -560,9 +594,10 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                 c.out[idx] = o;
             }
         }
+        wave_mark_done(c.done, active && status != 0 && c4 == 0 && !qhz, tag_ticket(c, tag));
         // body of the next trip: on its way while this trip's results are stored
         KaBody bdN = {};
-        if (activeN) bdN = ka_fetch_body(c, QA + qposN, cap, c4, hdN.idx);
+        if (activeN) bdN = ka_fetch_body(c, QA + qposN, cap, c4, tag_slot(c, hdN.tag));
         // ---- ... or hand it over to the step round: one queue-B slot per surviving quad -------------------------
         {
             bool go = active && (status == 0);
@@ -588,7 +623,7 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                     qb[(B_SDIAG + k) * cap] = 0.;
                 }
                 if (c4 == 0) {
-                    qb[A_IDX * cap] = pack2(idx, 0);
+                    qb[A_IDX * cap] = pack2(tag, 0);
                     qb[A_LLIM1 * cap] = llim1; qb[A_FNORM * cap] = fnorm; qb[A_PAR * cap] = par_in; qb[A_DELTA * cap] = delta;
                     qb[A_XNORM * cap] = xnorm; qb[A_ITER * cap] = pack2(niter, nfev);
                     qb[B_GNORM * cap] = gnorm; qb[B_IPVT * cap] = pack2((int)ipvt, 0);
@@ -636,8 +671,8 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
         const int slot_in = live ? (base + lane) : 0;
         const long long cap = c.cap;
         const double* qb = QB + slot_in;
-        int idx, dummy, niter, nfev, ipvt_i;
-        unpack2(qb[A_IDX * cap], &idx, &dummy);
+        int tag, dummy, niter, nfev, ipvt_i;
+        unpack2(qb[A_IDX * cap], &tag, &dummy);
         unpack2(qb[A_ITER * cap], &niter, &nfev);
         unpack2(qb[B_IPVT * cap], &ipvt_i, &dummy);
         const unsigned ipvt = (unsigned)ipvt_i;
@@ -678,7 +713,7 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
                 const int atC = wave_reserve(cntC, park);
                 if (park) {
                     double* qn = QC + atC;
-                    qn[A_IDX * cap] = pack2(idx, 0);
+                    qn[A_IDX * cap] = pack2(tag, 0);
 #pragma unroll
                     for (int k = 0; k < FSQ_NP; k++) {
                         qn[(A_X + k) * cap] = xq[k]; qn[(A_DIAG + k) * cap] = q.dg[k];
@@ -763,7 +798,7 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
         {
             double g[FSQ_NPIX], data[FSQ_NPIX];
             asm volatile("" ::: "memory");          // the pixels are fetched here, not carried through lmpar
-            roi_compact(c, idx, data);
+            roi_compact(c, tag_slot(c, tag), data);
             fsq_model(wa2, g);
 #pragma unroll
             for (int i = 0; i < FSQ_NPIX; i++) wa4[i] = data[i] - g[i];
@@ -814,7 +849,7 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
                 xs = fsq_fma(t, t, xs);
             }
 #pragma unroll
-            for (int i = 0; i < FSQ_NPIX; i++) if (live) c.fvec[(size_t)idx * FSQ_NPIX + i] = wa4[i];
+            for (int i = 0; i < FSQ_NPIX; i++) if (live) c.fvec[(size_t)tag_slot(c, tag) * FSQ_NPIX + i] = wa4[i];
             xnorm = fsq_sqrt(xs);
             fnorm = fnorm1;
             niter = niter + 1;
@@ -843,8 +878,9 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
 #pragma unroll
             for (int k = 0; k < FSQ_NP; k++) o.x[k] = xq[k];
             o.status = status; o.niter = niter; o.nfev = nfev; o.pad = 0;
-            c.out[idx] = o;
+            c.out[tag_slot(c, tag)] = o;
         }
+        wave_mark_done(c.done, live && status != 0, tag_ticket(c, tag));
         {
             // accepted -> a new Jacobian (queue A); rejected -> another pass with the same, mutated R (queue B)
             const bool toA = live && status == 0 && accepted, toB = live && status == 0 && !accepted;
@@ -852,7 +888,7 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
             const int atB = wave_reserve(cntB_next, toB);
             if (toA || toB) {
                 double* qn = toA ? (QA_next + atA) : (QB_next + atB);
-                qn[A_IDX * cap] = pack2(idx, 0);
+                qn[A_IDX * cap] = pack2(tag, 0);
 #pragma unroll
                 for (int k = 0; k < FSQ_NP; k++) { qn[(A_X + k) * cap] = xq[k]; qn[(A_DIAG + k) * cap] = q.dg[k]; }
                 qn[A_LLIM1 * cap] = llim1; qn[A_FNORM * cap] = fnorm; qn[A_PAR * cap] = par; qn[A_DELTA * cap] = delta;
@@ -876,18 +912,19 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
 
 // ---------------------------------------------------------------------------------------------------
 // fit-quality metrics and the output row (pflib.py:461-475)
-__global__ void __launch_bounds__(64) kfinish(Ctx c, FsqRow* __restrict__ rows)
+__global__ void __launch_bounds__(64) kfinish(Ctx c, BatchArgs b, FsqRow* __restrict__ rows)
 {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c.n) return;
-    const FitOut S = c.out[i];
+    if (i >= b.n) return;
+    const long long slot = b.base + i;
+    const FitOut S = c.out[slot];
     double data[FSQ_NPIX], p[FSQ_NP];
-    roi_compact(c, i, data);
+    roi_compact(c, slot, data);
 #pragma unroll
     for (int k = 0; k < FSQ_NP; k++) p[k] = S.x[k];
-    const double vmax = c.stat[i].vmax, vmean = c.stat[i].vmean;
+    const double vmax = c.stat[slot].vmax, vmean = c.stat[slot].vmean;
     int h = 2, w = 2, field = 0;
-    if (c.from_image) { field = c.cand[3 * i]; h = c.cand[3 * i + 1]; w = c.cand[3 * i + 2]; }
+    if (b.from_image) { field = b.cand[3 * i]; h = b.cand[3 * i + 1]; w = b.cand[3 * i + 2]; }
     double fit[FSQ_NPIX];
     fsq_model(p, fit);
     double num = 0.0, den = 0.0, rm = 0.0;
@@ -935,7 +972,7 @@ __global__ void kdivcheck(const double* __restrict__ num, const double* __restri
     const double q0 = a / d, q1 = fsq_div_by(a, k);
     if (fsq_bits(q0) != fsq_bits(q1)) atomicAdd(bad, 1ull);
 }
-long long g_last_slow = 0;
+std::atomic<long long> g_last_slow{0};
 
 __global__ void krotcheck(const double* __restrict__ t, long long n, unsigned long long* bad)
 {
@@ -1017,7 +1054,7 @@ extern "C" int fsq_selftest_division(const double* d_num, const double* d_den, i
     return FSQ_OK;
 }
 
-extern "C" int64_t fsq_fit_last_slow_count(void) { return g_last_slow; }
+extern "C" int64_t fsq_fit_last_slow_count(void) { return g_last_slow.load(); }
 
 #ifdef FSQ_PHASE_PROFILE
 extern "C" int fsq_debug_rphase(unsigned long long* out16, int reset)
@@ -1032,23 +1069,43 @@ extern "C" int fsq_debug_rphase(unsigned long long* out16, int reset)
 
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-extern "C" int64_t fsq_fit_workspace_bytes(int64_t n)
+// ---- host side: the rounds engine ---------------------------------------------------------------------------------
+// One engine = a pool of by-candidate slots + the work queues + the round loop.  Batches of candidates are SUBMITTED to
+// it (kinit appends their fresh records to the current Jacobian queue) and every round advances all fits in flight,
+// whatever batch they belong to; a batch is FINISHED (kfinish writes its rows) when its done counter reaches its size.
+// fsq_fit_candidates / fsq_fit_rois run one batch through a temporary engine laid out in the caller's workspace;
+// FsqFitQueue (include/fsq.h) keeps an engine alive across batches, so that the long latency-bound tail of one batch
+// (a fit may need 200 sequential iterations) rides along in the full launches of the batches submitted after it.
+namespace {
+enum { CTL_SLOW_TOTAL = 8, CTL_SLOW_CNT = 9, CTL_DONE = 16, CTL_INTS = CTL_DONE + FSQ_MAX_TICKETS };
+
+struct RoundsCfg {
+    int trips = 1, lm_first = FSQ_LMPAR_FIRST, sync_mask = 3, force_slow_mod = 0, force_redo = 0, no_wave_prio = 0, trace = 0;
+    int max_rounds = 0;
+    long long two_pass_min = 524288, hiprio_below = 200000;
+};
+RoundsCfg read_cfg()
 {
-    if (n < 0) return FSQ_EINVAL;
-    const size_t cap = (size_t)n + 64;
-    size_t b = 4096;
-    b += al256(cap * 64) + al256(cap * FSQ_NPIX * 8) + al256(cap * sizeof(FitOut)) + al256(cap * sizeof(FitStat));
-    b += 2 * al256(cap * A_LEN * 8) + 2 * al256(cap * B_LEN * 8) + al256(cap * C_LEN * 8) + al256(cap * A_LEN * 8);
-    return (int64_t)b;
+    RoundsCfg g;
+    const char* e;
+    if ((e = getenv("FSQ_DEBUG_FORCE_SLOW")) != nullptr) g.force_slow_mod = atoi(e);
+    if ((e = getenv("FSQ_DEBUG_FORCE_NORM_RECOMPUTE")) != nullptr) g.force_redo = atoi(e) ? 1 : 0;
+    if ((e = getenv("FSQ_TRIPS_PER_BLOCK")) != nullptr) g.trips = atoi(e);
+    if ((e = getenv("FSQ_LMPAR_FIRST_ITERS")) != nullptr && atoi(e) >= 1 && atoi(e) <= 10) g.lm_first = atoi(e);
+    if ((e = getenv("FSQ_TWO_PASS_MIN")) != nullptr) g.two_pass_min = atoll(e);
+    if ((e = getenv("FSQ_HIPRIO_BELOW")) != nullptr) g.hiprio_below = atoll(e);
+    if ((e = getenv("FSQ_SYNC_EVERY")) != nullptr && atoi(e) >= 1) g.sync_mask = atoi(e) - 1;     // power of two
+    if (getenv("FSQ_NO_WAVE_PRIO")) g.no_wave_prio = 1;
+    if (getenv("FSQ_DEBUG_TRACE")) g.trace = 1;
+    if ((e = getenv("FSQ_DEBUG_MAX_ROUNDS")) != nullptr) g.max_rounds = atoi(e);
+    return g;
 }
 
-// Host driver of the rounds.  Synchronises the stream every few rounds to read the queue sizes.
-// High-priority streams for the late rounds.  Once few fits are left a round is a handful of small kernels whose
-// latency is the whole cost; when another stream (another lane of engine.LanePipeline) is busy with the large early
-// rounds of its own batch, the dispatcher would queue those small kernels behind whole large ones.  From the first
-// host look that finds fewer than FSQ_HIPRIO_BELOW live fits the rounds therefore continue on a stream of the highest
-// priority (the switch happens right after a stream synchronisation, so no event is needed).
-namespace {
+// High-priority streams for the late rounds of a stand-alone batch.  Once few fits are left a round is a handful of
+// small kernels whose latency is the whole cost; when another stream (another lane of engine.LanePipeline) is busy with
+// the large early rounds of its own batch, the dispatcher would queue those small kernels behind whole large ones.  From
+// the first host look that finds fewer than FSQ_HIPRIO_BELOW live fits the rounds therefore continue on a stream of the
+// highest priority (the switch happens right after a stream synchronisation, so no event is needed).
 struct HiStream { hipStream_t s; int dev; bool busy; };
 std::mutex g_hi_mu;
 std::vector<HiStream> g_hi;
@@ -1072,76 +1129,131 @@ void hi_release(hipStream_t st)
     for (auto& h : g_hi)
         if (h.s == st) h.busy = false;
 }
-struct HiGuard { hipStream_t s = nullptr; ~HiGuard() { if (s) hi_release(s); } };
+
+enum { FSQ_TICKET_BITS = 5 };
+static_assert((1 << FSQ_TICKET_BITS) == FSQ_MAX_TICKETS, "ticket bits");
+enum { T_FREE = 0, T_FLIGHT = 1, T_FINISHED = 2 };
+struct Batch { BatchArgs a; FsqRow* rows; int state; hipEvent_t ev; };
+
+size_t layout_bytes(size_t pool, size_t qcap)
+{
+    size_t b = 4096;
+    b += al256(pool * 64) + al256(pool * FSQ_NPIX * 8) + al256(pool * sizeof(FitOut)) + al256(pool * sizeof(FitStat));
+    b += 2 * al256(qcap * A_LEN * 8) + 2 * al256(qcap * B_LEN * 8) + al256(qcap * C_LEN * 8) + al256(qcap * A_LEN * 8);
+    return b;
+}
 }  // namespace
 
-int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_cand, int64_t n, int mode, bool from_image,
-                          FsqRow* d_rows, void* d_ws, int64_t ws_bytes, hipStream_t s_user)
-{
-    hipStream_t s = s_user;
-    HiGuard hi;
-    if (ws_bytes < fsq_fit_workspace_bytes(n) || !d_ws) return FSQ_ENOMEM;
-    if (n > 2000000000ll) return FSQ_ENOTIMPL;
-    const size_t cap = (size_t)n + 64;
-    unsigned char* ws = (unsigned char*)d_ws;
-    int* ctl = (int*)ws;            // per ping/pong set: {queue A, queue B, -, queue C}; [8] slow total, [9] slow queue
-    size_t o = 4096;
+struct FsqFitQueue {
     Ctx c;
-    c.src = d_src; c.cand = d_cand; c.H = H; c.W = W; c.n = n; c.from_image = from_image ? 1 : 0; c.cap = (long long)cap;
-    c.roi = (uint16_t*)(ws + o); o += al256(cap * 64);
-    c.fvec = (double*)(ws + o); o += al256(cap * FSQ_NPIX * 8);
-    c.out = (FitOut*)(ws + o); o += al256(cap * sizeof(FitOut));
-    c.stat = (FitStat*)(ws + o); o += al256(cap * sizeof(FitStat));
-    double* QA[2]; double* QB[2];
-    QA[0] = (double*)(ws + o); o += al256(cap * A_LEN * 8);
-    QA[1] = (double*)(ws + o); o += al256(cap * A_LEN * 8);
-    QB[0] = (double*)(ws + o); o += al256(cap * B_LEN * 8);
-    QB[1] = (double*)(ws + o); o += al256(cap * B_LEN * 8);
-    int* cA[2] = {ctl + 0, ctl + 4};
-    int* cB[2] = {ctl + 1, ctl + 5};
-    int* cC[2] = {ctl + 3, ctl + 7};
-    double* QC = (double*)(ws + o); o += al256(cap * C_LEN * 8);
-    double* SQ = (double*)(ws + o); o += al256(cap * A_LEN * 8);
-    int* cSlow = ctl + 9;
+    size_t pool = 0, qcap = 0;
+    int* ctl = nullptr;
+    double *QA[2], *QB[2], *QC = nullptr, *SQ = nullptr;
+    int *cA[2], *cB[2], *cC[2], *cSlow = nullptr;
+    RoundsCfg cfg;
+    bool ref = true, single_call = false;
+    int cus = 256;
+    long long round = 0;                                   // rounds run so far; set (round & 1) is consumed next
+    long long boundA = 0, boundB = 0, alive = 0, slow_pending = 0;     // host-side upper bounds of the queue sizes
+    long long head = 0;                                    // ring allocator over the pool slots
+    Batch b[FSQ_MAX_TICKETS];
+    hipStream_t s = nullptr, s_finish = nullptr, hi = nullptr;
+    int h_ctl[CTL_INTS];
+    void* owned_ws = nullptr;
+
+    int init(void* d_ws, int64_t ws_bytes, size_t pool_, size_t qcap_, int mode, hipStream_t stream, bool single)
     {
-        const char* e = getenv("FSQ_DEBUG_FORCE_SLOW");
-        c.force_slow_mod = e ? atoi(e) : 0;
-        e = getenv("FSQ_DEBUG_FORCE_NORM_RECOMPUTE");
-        c.force_redo = (e && atoi(e)) ? 1 : 0;
+        if (!d_ws || (size_t)ws_bytes < layout_bytes(pool_, qcap_)) return FSQ_ENOMEM;
+        if (pool_ > 2000000000ull || qcap_ > 2000000000ull) return FSQ_ENOTIMPL;
+        pool = pool_; qcap = qcap_; s = s_finish = stream; single_call = single;
+        ref = ((mode & 0xff) == FSQ_MODE_REF);
+        cfg = read_cfg();
+        unsigned char* ws = (unsigned char*)d_ws;
+        ctl = (int*)ws;     // per ping/pong set: {queue A, queue B, -, queue C}; [8] slow total, [9] slow queue, [16..] done
+        size_t o = 4096;
+        c.cap = (long long)qcap;
+        c.roi = (uint16_t*)(ws + o); o += al256(pool * 64);
+        c.fvec = (double*)(ws + o); o += al256(pool * FSQ_NPIX * 8);
+        c.out = (FitOut*)(ws + o); o += al256(pool * sizeof(FitOut));
+        c.stat = (FitStat*)(ws + o); o += al256(pool * sizeof(FitStat));
+        QA[0] = (double*)(ws + o); o += al256(qcap * A_LEN * 8);
+        QA[1] = (double*)(ws + o); o += al256(qcap * A_LEN * 8);
+        QB[0] = (double*)(ws + o); o += al256(qcap * B_LEN * 8);
+        QB[1] = (double*)(ws + o); o += al256(qcap * B_LEN * 8);
+        QC = (double*)(ws + o); o += al256(qcap * C_LEN * 8);
+        SQ = (double*)(ws + o); o += al256(qcap * A_LEN * 8);
+        cA[0] = ctl + 0; cA[1] = ctl + 4; cB[0] = ctl + 1; cB[1] = ctl + 5; cC[0] = ctl + 3; cC[1] = ctl + 7;
+        cSlow = ctl + CTL_SLOW_CNT;
+        c.slow_total = ctl + CTL_SLOW_TOTAL; c.done = ctl + CTL_DONE;
+        c.tshift = single ? 31 : 32 - FSQ_TICKET_BITS;
+        if (!single && pool_ >= (1ull << c.tshift)) return FSQ_ENOTIMPL;
+        c.wave_prio = 0; c.force_redo = cfg.force_redo; c.force_slow_mod = cfg.force_slow_mod;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        for (auto& t : b) { t.state = T_FREE; t.ev = nullptr; t.rows = nullptr; }
+        FSQ_HIP_CHECK(hipMemsetAsync(ctl, 0, CTL_INTS * sizeof(int), s));
+        return FSQ_OK;
     }
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    int h_init[12] = {(int)n, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    c.slow_total = ctl + 8;
-    c.wave_prio = 0;
-    FSQ_HIP_CHECK(hipMemcpyAsync(ctl, h_init, sizeof(h_init), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(kinit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c, QA[0]);
-    const bool ref = (mode == FSQ_MODE_REF);
-    // Grid sizing: one block per loop trip (16 fits in kA, 64 in kB), so blocks retire continuously.  The hardware
-    // dispatcher then balances the very uneven trip times, and the small late-round kernels of ANOTHER stream
-    // (engine.LanePipeline) find free CU slots between them.  FSQ_TRIPS_PER_BLOCK=t gives every block t trips;
-    // t = 0 launches resident grids (8 waves per CU) that stride over the queue - measured 7% slower.
-    long long full = (long long)cus * 8;
-    int trips = 1, lm_first_cfg = FSQ_LMPAR_FIRST, sync_mask = 3;
-    long long two_pass_min = 524288, hiprio_below = 200000;
+
+    // contiguous range of n pool slots that no batch in flight owns (ring order); -1 if there is none right now
+    long long alloc_slots(long long n)
     {
-        const char* e = getenv("FSQ_TRIPS_PER_BLOCK");
-        if (e) trips = atoi(e);
-        if ((e = getenv("FSQ_LMPAR_FIRST_ITERS")) != nullptr && atoi(e) >= 1 && atoi(e) <= 10) lm_first_cfg = atoi(e);
-        if ((e = getenv("FSQ_TWO_PASS_MIN")) != nullptr) two_pass_min = atoll(e);
-        if ((e = getenv("FSQ_HIPRIO_BELOW")) != nullptr) hiprio_below = atoll(e);
-        if ((e = getenv("FSQ_SYNC_EVERY")) != nullptr && atoi(e) >= 1) sync_mask = atoi(e) - 1;     // power of two
+        if ((size_t)n > pool) return -1;
+        long long at = head;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            if ((size_t)(at + n) > pool) at = 0;
+            bool clash = false;
+            for (const auto& t : b)
+                if (t.state == T_FLIGHT && at < t.a.base + t.a.n && t.a.base < at + n) { clash = true; break; }
+            if (!clash) { head = at + n; return at; }
+            if (at == 0) break;
+            at = 0;
+        }
+        return -1;
     }
-    int h_cnt[12];
-    long long boundA = n, boundB = 0, alive = n;             // host-side upper bounds of the queue sizes
-    long long slow_pending = 0;                              // slow-queue length at the last look
-    for (int round = 0;; round++) {
-        const int cur = round & 1, nxt = cur ^ 1;
+
+    int submit(const uint16_t* src, int H, int W, const int32_t* cand, long long n, bool from_image, FsqRow* rows, int* ticket)
+    {
+        if (n < 0 || (n > 0 && (!src || !rows || (from_image && !cand)))) return FSQ_EINVAL;
+        int t = -1;
+        for (int k = 0; k < FSQ_MAX_TICKETS; k++)
+            if (b[k].state == T_FREE) { t = k; break; }
+        if (t < 0) return FSQ_EAGAIN;
+        if ((size_t)(alive + n) > qcap) return FSQ_EAGAIN;
+        const long long base = n > 0 ? alloc_slots(n) : 0;
+        if (base < 0) return FSQ_EAGAIN;
+        Batch& B = b[t];
+        B.a.src = src; B.a.cand = cand; B.a.H = H; B.a.W = W; B.a.n = n; B.a.from_image = from_image ? 1 : 0;
+        B.a.base = base; B.a.ticket = t; B.rows = rows;
+        if (!single_call && !B.ev) FSQ_HIP_CHECK(hipEventCreateWithFlags(&B.ev, hipEventDisableTiming));
+        if (n == 0) {
+            B.state = T_FINISHED;
+            if (B.ev) FSQ_HIP_CHECK(hipEventRecord(B.ev, s));
+        } else {
+            const int cur = (int)(round & 1);
+            FSQ_HIP_CHECK(hipMemsetAsync(c.done + t, 0, sizeof(int), s));
+            hipLaunchKernelGGL(kinit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c, B.a, QA[cur], cA[cur]);
+            B.state = T_FLIGHT;
+            boundA += n; alive += n;
+        }
+        if (ticket) *ticket = t;
+        return FSQ_OK;
+    }
+
+    // One round: Jacobian round over queue A of set cur (+ the slow queue), step round over queue B; results in set nxt.
+    int one_round()
+    {
+        const int cur = (int)(round & 1), nxt = cur ^ 1;
+        // Grid sizing: one block per loop trip (16 fits in kA, 64 in kB), so blocks retire continuously.  The hardware
+        // dispatcher then balances the very uneven trip times, and small kernels of ANOTHER stream find free CU slots
+        // between them.  FSQ_TRIPS_PER_BLOCK=t gives every block t trips; t = 0 launches resident grids (8 waves per
+        // CU) that stride over the queue - measured 7% slower.
+        const long long full = (long long)cus * 8;
         long long nB = boundA + boundB;
         if (nB > alive) nB = alive;
         long long gA = (boundA + 15) / 16;          // kA: a block per trip unless built with FSQ_KA_PIPELINE
         if (KA_PIPELINE) {
-            if (trips > 0) gA = (gA + trips - 1) / trips;
+            if (cfg.trips > 0) gA = (gA + cfg.trips - 1) / cfg.trips;
             else if (gA > full) gA = full;
         }
         if (gA > 0)         // (also zeroes the counters of set nxt)
@@ -1160,15 +1272,15 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
         }
         long long gB = (nB + 63) / 64;              // kB: a block per trip unless built with FSQ_KB_LOOP
         if (KB_LOOP) {
-            if (trips > 0) gB = (gB + trips - 1) / trips;
+            if (cfg.trips > 0) gB = (gB + cfg.trips - 1) / cfg.trips;
             else if (gB > full) gB = full;
         }
         if (gB > 0) {
-            // first pass over queue B, then the fits it parked in queue C (blocks beyond the C count leave at once)
+            // first pass over queue B, then the fits it parked in queue C (blocks beyond the C count leave at once).
             // With few fits left a round is pure launch + wave latency: lmpar then runs to the end in the first pass
             // (nothing is parked) and the resume launch is skipped.
-            const bool two_pass = nB > two_pass_min && lm_first_cfg < 10;
-            const int lm_first = two_pass ? lm_first_cfg : 10;
+            const bool two_pass = nB > cfg.two_pass_min && cfg.lm_first < 10;
+            const int lm_first = two_pass ? cfg.lm_first : 10;
             if (ref) {
                 hipLaunchKernelGGL((kB_step<true, false>), dim3((unsigned)gB), dim3(64), 0, s, c, QB[cur], cB[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur], lm_first);
                 if (two_pass) hipLaunchKernelGGL((kB_step<true, true>), dim3((unsigned)gB), dim3(64), 0, s, c, QC, cC[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur], 10);
@@ -1177,33 +1289,160 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
                 if (two_pass) hipLaunchKernelGGL((kB_step<false, true>), dim3((unsigned)gB), dim3(64), 0, s, c, QC, cC[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur], 10);
             }
         }
-        boundB = nB;                                         // every candidate of this round ends in A[nxt], B[nxt] or is done
-        boundA = boundB;
-        if ((round & sync_mask) == sync_mask) {                              // (rounds on empty queues cost a few empty launches)
-            FSQ_HIP_CHECK(hipMemcpyAsync(h_cnt, ctl, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
-            FSQ_HIP_CHECK(hipStreamSynchronize(s));
-            boundA = h_cnt[4 * nxt];
-            boundB = h_cnt[4 * nxt + 1];
-            alive = boundA + boundB;
-            g_last_slow = h_cnt[8];
-            slow_pending = h_cnt[9];
-            alive += slow_pending;
-            if (getenv("FSQ_DEBUG_TRACE")) fprintf(stderr, "round %d: A=%lld B=%lld slow=%lld total_slow=%d\n", round, boundA, boundB, slow_pending, h_cnt[8]);
-            if (boundA == 0 && boundB == 0 && slow_pending == 0) break;
-            if (!hi.s && alive < hiprio_below && n >= 4 * hiprio_below) {      // (small batches gain nothing)
-                hi.s = hi_acquire();
-                if (hi.s) s = hi.s;            // the user's stream is idle here: plain hand-over
-                c.wave_prio = getenv("FSQ_NO_WAVE_PRIO") ? 0 : 1;
-            }
+        boundB = nB;                                // every fit of this round ends in A[nxt], B[nxt] or is done
+        boundA = nB;
+        round++;
+        return FSQ_OK;
+    }
+
+    // Read the counters (synchronises the stream), refresh the bounds, finish the batches that are complete.
+    int look(int* newly_finished)
+    {
+        FSQ_HIP_CHECK(hipMemcpyAsync(h_ctl, ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, s));
+        FSQ_HIP_CHECK(hipStreamSynchronize(s));
+        const int cur = (int)(round & 1);
+        boundA = h_ctl[4 * cur];
+        boundB = h_ctl[4 * cur + 1];
+        slow_pending = h_ctl[CTL_SLOW_CNT];
+        alive = boundA + boundB + slow_pending;
+        g_last_slow.store(h_ctl[CTL_SLOW_TOTAL]);
+        if (cfg.trace) fprintf(stderr, "round %lld: A=%lld B=%lld slow=%lld total_slow=%d\n", round - 1, boundA, boundB, slow_pending, h_ctl[CTL_SLOW_TOTAL]);
+        int fin = 0;
+        for (auto& t : b) {
+            if (t.state != T_FLIGHT || h_ctl[CTL_DONE + t.a.ticket] < t.a.n) continue;
+            // (s_finish: a stand-alone call hands its rows over on the caller's stream, idle and ordered here)
+            hipLaunchKernelGGL(kfinish, dim3((unsigned)((t.a.n + 63) / 64)), dim3(64), 0, s_finish, c, t.a, t.rows);
+            if (t.ev) FSQ_HIP_CHECK(hipEventRecord(t.ev, s_finish));
+            t.state = T_FINISHED;
+            fin++;
         }
-        if (getenv("FSQ_DEBUG_MAX_ROUNDS") && round + 1 >= atoi(getenv("FSQ_DEBUG_MAX_ROUNDS"))) {
-            FSQ_HIP_CHECK(hipStreamSynchronize(s));
+        if (newly_finished) *newly_finished = fin;
+        if (single_call && !hi && alive > 0 && alive < cfg.hiprio_below && (long long)pool >= 4 * cfg.hiprio_below) {
+            hi = hi_acquire();                  // (small batches gain nothing)
+            if (hi) s = hi;                     // the user's stream is idle here: plain hand-over
+            c.wave_prio = cfg.no_wave_prio ? 0 : 1;
+        }
+        return FSQ_OK;
+    }
+
+    // Run rounds until a batch finishes, nothing is left, fewer than `alive_below` fits are alive, or `max_rounds` ran.
+    int advance(long long max_rounds, long long alive_below, long long* alive_out, int* finished_out)
+    {
+        int fin_total = 0;
+        long long ran = 0;
+        while (alive > 0) {
+            int rc = one_round();
+            if (rc != FSQ_OK) return rc;
+            ran++;
+            const bool stop = (max_rounds > 0 && ran >= max_rounds);
+            if (stop || (round & cfg.sync_mask) == 0) {      // (rounds on empty queues cost a few empty launches)
+                int fin = 0;
+                rc = look(&fin);
+                if (rc != FSQ_OK) return rc;
+                fin_total += fin;
+                if (stop || fin_total > 0 || alive < alive_below) break;
+            }
+            if (round > 100000000ll) return FSQ_EHIP;
+        }
+        FSQ_HIP_CHECK(hipGetLastError());
+        if (alive_out) *alive_out = alive;
+        if (finished_out) *finished_out = fin_total;
+        return FSQ_OK;
+    }
+
+    ~FsqFitQueue()
+    {
+        if (hi) hi_release(hi);
+        for (auto& t : b)
+            if (t.ev) (void)hipEventDestroy(t.ev);
+        if (owned_ws) (void)hipFree(owned_ws);
+    }
+};
+
+extern "C" int64_t fsq_fit_workspace_bytes(int64_t n)
+{
+    if (n < 0) return FSQ_EINVAL;
+    return (int64_t)layout_bytes((size_t)n + 64, (size_t)n + 64);
+}
+
+// One stand-alone batch: a temporary engine in the caller's workspace.  Returns when the last round has run; the
+// row-writing kernel is enqueued on the caller's stream.
+int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_cand, int64_t n, int mode, bool from_image,
+                          FsqRow* d_rows, void* d_ws, int64_t ws_bytes, hipStream_t s_user)
+{
+    if (n > 2000000000ll) return FSQ_ENOTIMPL;
+    if (ws_bytes < fsq_fit_workspace_bytes(n) || !d_ws) return FSQ_ENOMEM;
+    FsqFitQueue q;
+    int rc = q.init(d_ws, ws_bytes, (size_t)n + 64, (size_t)n + 64, mode, s_user, true);
+    if (rc != FSQ_OK) return rc;
+    rc = q.submit(d_src, H, W, d_cand, n, from_image, d_rows, nullptr);
+    if (rc != FSQ_OK) return rc;
+    while (q.alive > 0) {
+        rc = q.advance(q.cfg.max_rounds, 0, nullptr, nullptr);
+        if (rc != FSQ_OK) return rc;
+        if (q.cfg.max_rounds > 0) {             // debug: stop early, rows of unfinished fits are undefined
+            FSQ_HIP_CHECK(hipStreamSynchronize(q.s));
             break;
         }
-        if (round > 100000) return FSQ_EHIP;                 // cannot happen: every pass shrinks delta or accepts
     }
-    s = s_user;                     // the loop left right after a synchronisation: every round is complete
-    hipLaunchKernelGGL(kfinish, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, c, d_rows);
     FSQ_HIP_CHECK(hipGetLastError());
+    return FSQ_OK;
+}
+
+// ---- FsqFitQueue: the engine kept alive across batches (include/fsq.h) ------------------------------------------
+extern "C" int64_t fsq_fitq_workspace_bytes(int64_t pool_slots, int64_t queue_cap)
+{
+    if (pool_slots <= 0 || queue_cap <= 0) return FSQ_EINVAL;
+    return (int64_t)layout_bytes((size_t)pool_slots, (size_t)queue_cap);
+}
+
+extern "C" int fsq_fitq_create(FsqFitQueue** out, void* d_workspace, int64_t workspace_bytes, int64_t pool_slots,
+                               int64_t queue_cap, int mode, void* stream)
+{
+    if (!out || pool_slots <= 0 || queue_cap <= 0) return FSQ_EINVAL;
+    if (mode & ~1) return FSQ_EINVAL;
+    FsqFitQueue* q = new (std::nothrow) FsqFitQueue();
+    if (!q) return FSQ_ENOMEM;
+    int rc = q->init(d_workspace, workspace_bytes, (size_t)pool_slots, (size_t)queue_cap, mode, (hipStream_t)stream, false);
+    if (rc != FSQ_OK) { delete q; return rc; }
+    *out = q;
+    return FSQ_OK;
+}
+
+extern "C" int fsq_fitq_submit(FsqFitQueue* q, const uint16_t* d_img, int n_fields, int H, int W, const int32_t* d_cand,
+                               int64_t n, FsqRow* d_rows, int* ticket)
+{
+    if (!q || n_fields < 0 || H < 5 || W < 5) return FSQ_EINVAL;
+    return q->submit(d_img, H, W, d_cand, n, true, d_rows, ticket);
+}
+
+extern "C" int fsq_fitq_advance(FsqFitQueue* q, int64_t max_rounds, int64_t alive_below, int64_t* alive, int* finished)
+{
+    if (!q) return FSQ_EINVAL;
+    long long a = 0;
+    int rc = q->advance(max_rounds, alive_below, &a, finished);
+    if (alive) *alive = a;
+    return rc;
+}
+
+extern "C" int fsq_fitq_take(FsqFitQueue* q, int ticket, void* consumer_stream)
+{
+    if (!q || ticket < 0 || ticket >= FSQ_MAX_TICKETS || q->b[ticket].state == T_FREE) return FSQ_EINVAL;
+    Batch& B = q->b[ticket];
+    if (B.state != T_FINISHED) return 0;
+    if (B.ev && (hipStream_t)consumer_stream != q->s_finish) FSQ_HIP_CHECK(hipStreamWaitEvent((hipStream_t)consumer_stream, B.ev, 0));
+    B.state = T_FREE;
+    return 1;
+}
+
+extern "C" int64_t fsq_fitq_alive(const FsqFitQueue* q) { return q ? q->alive : FSQ_EINVAL; }
+extern "C" int64_t fsq_fitq_rounds(const FsqFitQueue* q) { return q ? q->round : FSQ_EINVAL; }
+
+extern "C" int fsq_fitq_destroy(FsqFitQueue* q)
+{
+    if (!q) return FSQ_EINVAL;
+    hipError_t e = hipStreamSynchronize(q->s);
+    delete q;
+    if (e != hipSuccess) { g_fsq_last_hip = e; return FSQ_EHIP; }
     return FSQ_OK;
 }

@@ -28,6 +28,16 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def world_size():
+    import torch.distributed as dist
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def get_rank():
+    import torch.distributed as dist
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
 def shard_fields(n_fields, rank, world):
     """Field indices of `rank` under the static round-robin partition (field i -> rank i mod world)."""
     return list(range(rank, n_fields, world))
@@ -57,6 +67,8 @@ def gather_tables(local_rows, dst=0):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local_rows, [int(local_rows.shape[0])]
     world, rank = dist.get_world_size(), dist.get_rank()
+    if dist.get_backend() == "gloo" and local_rows.is_cuda:      # (CPU rehearsal of the N > 1 path: gloo moves host memory)
+        local_rows = local_rows.cpu()
     n = torch.tensor([local_rows.shape[0]], dtype=torch.int64, device=local_rows.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n)
@@ -74,3 +86,149 @@ def gather_tables(local_rows, dst=0):
         for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local_rows.contiguous(), dst)]):
             w.wait()
     return None, counts
+
+
+class ShardedTables:
+    """Rank-side half of the peak-table exchange for a STREAM of batches (engine.StreamPipeline.run's on_done):
+    every batch's kept table goes to `dst` with gather_tables, in batch order on every rank, whatever order the
+    batches finished in locally (the gather is a collective: all ranks must issue it for the same batch)."""
+
+    def __init__(self, device, dst=0, keep_last=True):
+        self.dst, self.next, self.ready = dst, 0, {}
+        self.last = None            # (table, counts) of the most recent gather on dst
+
+    def push(self, j, eng, total):
+        self.ready[j] = eng.kept_table()[0]
+        self.flush()
+
+    def flush(self):
+        while self.next in self.ready:
+            self.last = gather_tables(self.ready.pop(self.next), self.dst)
+            self.next += 1
+
+
+def _partition(weights_or_n, world, partition):
+    if partition == "round_robin":
+        return [shard_fields(weights_or_n, r, world) for r in range(world)]
+    if partition == "lpt":
+        return [sorted(p) for p in lpt_partition(weights_or_n, world)]
+    raise ValueError("partition must be 'lpt' or 'round_robin'")
+
+
+def find_peptides_sharded(images, partition="lpt", dst=0, **find_peptides_parameters):
+    """pflib.find_peptides over a stack uint16[n, H, W] with the fields sharded over the ranks of the process group
+    (one process per GPU).  Every rank calls it with the same stack and parameters.
+
+    partition='lpt' balances the fields by candidate count with the reference's longest-processing-time rule
+    (pflib.parallel_image_batch, pflib.py:1043-1069: candidates are counted first, then the fields are dealt out);
+    'round_robin' gives field i to rank i mod world.  Each rank runs detect -> fit -> consolidate on its share; the
+    only exchange is the gather of the peak records to `dst` (RCCL p2p, gather_tables).  Returns the list of n dicts
+    (identical to pflib.find_peptides_batch on one GPU) on `dst` and None on the other ranks."""
+    import torch
+    import torch.distributed as dist
+    from . import _native as N
+    from . import engine as E
+    from . import pflib
+    world, rank = world_size(), get_rank()
+    if world == 1:
+        return pflib.find_peptides_batch(images, **find_peptides_parameters)
+    imgs = E.as_u16_fields(images)
+    if imgs.ndim != 3:
+        raise ValueError("images must have shape (n, H, W)")
+    n, H, W = imgs.shape
+    fp = dict(find_peptides_parameters)
+    radius = fp.get("consolidation_radius", 4)
+    if radius < 2:
+        raise ValueError("consolidation_radius must be at least 2")
+    if fp.get("fit_type", "gauss") != "gauss":
+        raise NotImplementedError("fit_type='monte_carlo' is not reproduced (pflib.py:117-177)")
+    prm = E.detect_params(fp.get("median_filter_size", 5), fp.get("correlation_matrix", pflib.default_correlation_matrix),
+                          fp.get("c_std", 2))
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    def run_share(idx, fit):
+        if not idx:
+            return None, None
+        eng = E.Engine(len(idx), H, W, device=dev)
+        d_img = E.to_device_u16(imgs[idx], dev)
+        if fit:
+            eng.run(d_img, prm, fp.get("r_2_threshold", 0.7), radius, N.MODE_REF, pflib.PY2_ROUND)
+        else:
+            eng.detect(d_img, prm)
+        return eng, d_img
+
+    if partition == "lpt":
+        # count candidates on a round-robin share, exchange the counts, deal the fields out
+        mine = shard_fields(n, rank, world)
+        eng, _ = run_share(mine, fit=False)
+        w = torch.zeros(n, dtype=torch.int64)
+        if eng is not None:
+            w[mine] = eng.counts[:len(mine)].cpu().long()
+        w = w.to(dev) if dist.get_backend() != "gloo" else w
+        dist.all_reduce(w)
+        parts = _partition([int(x) for x in w.cpu()], world, "lpt")
+        del eng
+    else:
+        parts = _partition(n, world, partition)
+    mine = parts[rank]
+    eng, d_img = run_share(mine, fit=True)
+    if eng is not None:
+        rec, offs = eng.peak_records(d_img)
+        per_field = (offs[1:] - offs[:-1]).to(torch.int32)
+        per_field = torch.where(eng.nkeep[:len(mine)] < 0, eng.nkeep[:len(mine)], per_field).reshape(-1, 1)
+    else:
+        rec = torch.empty((0, E.PEAK_RECORD_BYTES), dtype=torch.uint8, device=dev)
+        per_field = torch.empty((0, 1), dtype=torch.int32, device=dev)
+    table, _ = gather_tables(rec, dst)
+    fields, _ = gather_tables(per_field.contiguous(), dst)
+    if rank != dst:
+        return None
+    rows, fit, sub = E.split_peak_records(table.cpu().numpy())
+    nk = fields.cpu().numpy().reshape(-1)
+    order = [i for p in parts for i in p]                  # global field index of every gathered per-field entry
+    failed = set(int(k) for k in np.nonzero(nk < 0)[0])
+    offs = np.concatenate([[0], np.cumsum(np.maximum(nk, 0))])
+    dicts = pflib._records_to_dicts(rows, fit, sub, offs, failed)
+    out = [None] * n
+    for k, i in enumerate(order):
+        out[i] = dicts[k]
+    for d in out:
+        if isinstance(d, Exception):
+            raise d
+    return out
+
+
+def image_batch_sharded(image_paths, find_peptides_parameters=None, timestamp_epoch=None):
+    """pflib.parallel_image_batch with the ranks of the process group as its workers (pflib.py:1000-1111): the images
+    are read and their candidates counted (each rank takes a round-robin share of that), dealt out by the reference's
+    longest-processing-time rule, every rank runs pflib.image_batch on its share (writing its own pickle / CSV files:
+    the file system is the reference's gather too) and the per-rank result dicts are merged on all ranks."""
+    import torch.distributed as dist
+    from . import pflib
+    world, rank = world_size(), get_rank()
+    if timestamp_epoch is None:             # one timestamp for the whole job, as the reference's parent process takes
+        box = [pflib._py2_round(__import__("time").time())]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        timestamp_epoch = box[0]
+    paths = list(dict.fromkeys(os.path.abspath(p) for p in image_paths))
+    if world == 1:
+        return pflib.image_batch(paths, find_peptides_parameters, timestamp_epoch)
+    fp = dict(find_peptides_parameters or {})
+    det = {k: fp[k] for k in ("median_filter_size", "correlation_matrix", "c_std") if k in fp}
+    mine = shard_fields(len(paths), rank, world)
+    local = pflib._candidate_counts([paths[i] for i in mine], det)          # unreadable images count as None
+    gathered = [None] * world
+    dist.all_gather_object(gathered, list(zip(mine, local)))
+    counts = dict(kv for part in gathered for kv in part)
+    usable = [i for i in range(len(paths)) if counts.get(i) is not None]
+    parts = lpt_partition([counts[i] for i in usable], world)
+    my_paths = [paths[usable[k]] for k in sorted(parts[rank])]
+    res = pflib.image_batch(my_paths, find_peptides_parameters, timestamp_epoch)
+    merged = [None] * world
+    dist.all_gather_object(merged, res)
+    out = {}
+    for part in merged:
+        for k, v in part.items():
+            out.setdefault(k, v)
+    return out

@@ -57,6 +57,18 @@ def detect_params(median_filter_size, correlation_matrix, c_std):
     return p
 
 
+PEAK_RECORD_BYTES = 128 + 200 + 50
+
+
+def split_peak_records(rec):
+    """uint8[k, PEAK_RECORD_BYTES] (host) -> (rows FsqRow[k], fit_img float64[k, 5, 5], sub_img int64[k, 5, 5])."""
+    rec = np.ascontiguousarray(rec).reshape(-1, PEAK_RECORD_BYTES)
+    rows = np.ascontiguousarray(rec[:, :128]).view(N.ROW_DTYPE).reshape(-1)
+    fit = np.ascontiguousarray(rec[:, 128:328]).view(np.float64).reshape(-1, 5, 5)
+    sub = np.ascontiguousarray(rec[:, 328:378]).view(np.uint16).reshape(-1, 5, 5).astype(np.int64)
+    return rows, fit, sub
+
+
 class DeviceBatch:
     """Results of one detect+fit+consolidate pass, still on the GPU."""
     __slots__ = ("n_fields", "H", "W", "cand", "counts", "offsets", "rows", "keep", "nkeep", "total", "thr")
@@ -65,7 +77,10 @@ class DeviceBatch:
 class Engine:
     """Re-usable buffers for a fixed (n_fields, H, W) batch shape on one GPU."""
 
-    def __init__(self, n_fields, H, W, device=None, cand_per_field=None):
+    def __init__(self, n_fields, H, W, device=None, cand_per_field=None, fit_workspace=True, shared_ws=None):
+        """fit_workspace=False: the LM fit runs in a FitQueue, which owns the solver state (StreamPipeline).
+        shared_ws: a uint8 device tensor used as the detection / consolidation workspace instead of a private
+        one - for engines whose detect and consolidate calls are all enqueued on ONE stream."""
         torch = _torch()
         self.torch = torch
         self.dev = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
@@ -75,7 +90,13 @@ class Engine:
         ws2 = self.L.fsq_consolidate_workspace_bytes(self.n_fields, self.H, self.W)
         if ws < 0 or ws2 < 0:
             raise ValueError("invalid batch shape")
-        self.ws = torch.empty(max(ws, ws2), dtype=torch.uint8, device=self.dev)
+        if shared_ws is not None:
+            if shared_ws.numel() < max(ws, ws2):
+                raise ValueError("shared_ws is smaller than workspace_bytes(%d, %d, %d)" % (self.n_fields, self.H, self.W))
+            self.ws = shared_ws
+        else:
+            self.ws = torch.empty(max(ws, ws2), dtype=torch.uint8, device=self.dev)
+        self._fit_workspace = bool(fit_workspace)
         self.counts = torch.zeros(self.n_fields + 1, dtype=torch.int32, device=self.dev)
         self.offsets = torch.zeros(self.n_fields + 1, dtype=torch.int32, device=self.dev)
         self.nkeep = torch.zeros(self.n_fields + 1, dtype=torch.int32, device=self.dev)
@@ -89,7 +110,8 @@ class Engine:
         self.cand = torch.empty((self.cap, 3), dtype=torch.int32, device=self.dev)
         self.rows = torch.empty((self.cap, 128), dtype=torch.uint8, device=self.dev)
         self.keep = torch.empty(self.cap, dtype=torch.int32, device=self.dev)
-        self.fit_ws = torch.empty(self.L.fsq_fit_workspace_bytes(self.cap), dtype=torch.uint8, device=self.dev)
+        self.fit_ws = (torch.empty(self.L.fsq_fit_workspace_bytes(self.cap), dtype=torch.uint8, device=self.dev)
+                       if self._fit_workspace else None)
 
     def _stream(self):
         return self.torch.cuda.current_stream(self.dev).cuda_stream
@@ -109,7 +131,14 @@ class Engine:
             return self.detect(d_img, prm)
         return total
 
+    @staticmethod
+    def workspace_bytes(n_fields, H, W):
+        L = N.lib()
+        return max(L.fsq_detect_workspace_bytes(n_fields, H, W), L.fsq_consolidate_workspace_bytes(n_fields, H, W))
+
     def fit(self, d_img, total, mode=N.MODE_REF):
+        if self.fit_ws is None:
+            raise RuntimeError("this Engine was created without a fit workspace (its fits run in a FitQueue)")
         rc = self.L.fsq_fit_candidates(d_img.data_ptr(), self.n_fields, self.H, self.W, self.cand.data_ptr(), total,
                                        mode, self.rows.data_ptr(), self.fit_ws.data_ptr(), self.fit_ws.numel(),
                                        self._stream())
@@ -131,36 +160,60 @@ class Engine:
         self.consolidate(r2_threshold, radius, py2_round)
         return total
 
+    # ---- the peak table ---------------------------------------------------------------------
+    def kept_table(self):
+        """The kept peaks of all fields as one contiguous device table in field order (fsq_kept_rows):
+        -> (uint8[k, 128] FsqRow bytes, int32[n_fields + 1] per-field offsets into it).  Reads the kept count
+        (synchronises the current stream)."""
+        torch = self.torch
+        k = int(self.nkeep[self.n_fields].item())
+        table = torch.empty((max(k, 0), 128), dtype=torch.uint8, device=self.dev)
+        offs = torch.empty(self.n_fields + 1, dtype=torch.int32, device=self.dev)
+        rc = self.L.fsq_kept_rows(self.rows.data_ptr(), self.keep.data_ptr(), self.offsets.data_ptr(), self.nkeep.data_ptr(),
+                                  self.n_fields, table.data_ptr(), table.shape[0], offs.data_ptr(), self._stream())
+        N.check(rc, "fsq_kept_rows")
+        return table, offs
+
+    def fit_images(self, table):
+        """fit_img of every row of a kept table (gaussfitter.py:253) -> float64[k, 25] on the device."""
+        fit = self.torch.empty((table.shape[0], 25), dtype=self.torch.float64, device=self.dev)
+        if table.shape[0]:
+            N.check(self.L.fsq_fit_images(table.data_ptr(), None, table.shape[0], fit.data_ptr(), self._stream()),
+                    "fsq_fit_images")
+        return fit
+
+    def peak_records(self, d_img):
+        """Everything pflib's 12-tuple holds, per kept peak, as one device byte table uint8[k, PEAK_RECORD_BYTES]:
+        the FsqRow (128 B), fit_img float64[25] (200 B), sub_img uint16[25] (50 B) - the unit of the multi-GPU
+        gather.  -> (records, per-field offsets int32[n_fields + 1])."""
+        torch = self.torch
+        table, offs = self.kept_table()
+        k = table.shape[0]
+        fit = self.fit_images(table)
+        ints = table[:, 96:128].contiguous().view(torch.int32)            # h, w, field, status, niter, nfev, key_h, key_w
+        d = torch.arange(-2, 3, device=self.dev)
+        hh = (ints[:, 0].long()[:, None, None] + d[None, :, None]).expand(k, 5, 5)
+        ww = (ints[:, 1].long()[:, None, None] + d[None, None, :]).expand(k, 5, 5)
+        ff = ints[:, 2].long()[:, None, None].expand(k, 5, 5)
+        sub = d_img[ff, hh, ww].contiguous()                              # int16-typed uint16 pixels (pflib.py:443)
+        rec = torch.cat([table, fit.view(torch.uint8).reshape(k, 200), sub.view(torch.uint8).reshape(k, 50)], dim=1)
+        return rec, offs
+
     # ---- host-side extraction --------------------------------------------------------------
-    def kept_tables(self, total):
+    def kept_tables(self, total=None):
         """Copy the consolidated tables to the host: list (per field) of (rows, fit_imgs) or None when the
         reference's re-key assertion fired for that field."""
-        torch = self.torch
         nkeep = self.nkeep.cpu().numpy()
-        offsets = self.offsets.cpu().numpy()
-        keep = self.keep[:max(total, 1)].cpu().numpy()
-        idx_parts = [keep[offsets[f]:offsets[f] + max(int(nkeep[f]), 0)] for f in range(self.n_fields)]
-        idx = np.concatenate(idx_parts) if idx_parts else np.zeros(0, np.int32)
+        table, offs = self.kept_table()
+        fit = self.fit_images(table).cpu().numpy().reshape(-1, 5, 5)
+        rows = table.cpu().numpy().view(N.ROW_DTYPE).reshape(-1)
+        offs = offs.cpu().numpy()
         out = []
-        if len(idx):
-            d_idx = torch.from_numpy(idx.astype(np.int64)).to(self.dev)
-            rows = self.rows[:total].index_select(0, d_idx).cpu().numpy().view(N.ROW_DTYPE).reshape(-1)
-            fit = torch.empty((len(idx), 25), dtype=torch.float64, device=self.dev)
-            d_idx32 = d_idx.to(torch.int32)
-            rc = self.L.fsq_fit_images(self.rows.data_ptr(), d_idx32.data_ptr(), len(idx), fit.data_ptr(), self._stream())
-            N.check(rc, "fsq_fit_images")
-            fit = fit.cpu().numpy().reshape(-1, 5, 5)
-        else:
-            rows = np.zeros(0, N.ROW_DTYPE)
-            fit = np.zeros((0, 5, 5))
-        pos = 0
         for f in range(self.n_fields):
-            k = int(nkeep[f])
-            if k < 0:
+            if int(nkeep[f]) < 0:
                 out.append(None)
                 continue
-            out.append((rows[pos:pos + k], fit[pos:pos + k]))
-            pos += k
+            out.append((rows[offs[f]:offs[f + 1]], fit[offs[f]:offs[f + 1]]))
         return out
 
     def all_rows(self, total):
@@ -211,6 +264,156 @@ class LanePipeline:
             t.join()
         if errs:
             raise errs[0]
+
+
+class FitQueue:
+    """The LM-fit engine kept alive across batches (fsq_fitq_* of include/fsq.h): batches are submitted while
+    earlier ones are still finishing and every round advances all fits in flight, so the long latency-bound tail
+    of one batch rides along in the full launches of the next ones."""
+
+    def __init__(self, pool_slots, queue_cap, mode=N.MODE_REF, device=None, stream=None):
+        torch = _torch()
+        self.torch = torch
+        self.dev = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
+        self.L = N.lib()
+        self.stream = stream or torch.cuda.Stream(device=self.dev)
+        nbytes = self.L.fsq_fitq_workspace_bytes(int(pool_slots), int(queue_cap))
+        if nbytes < 0:
+            raise ValueError("invalid fit queue size")
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+        self.pool_slots, self.queue_cap = int(pool_slots), int(queue_cap)
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.dev):
+            N.check(self.L.fsq_fitq_create(ctypes.byref(h), self.ws.data_ptr(), nbytes, self.pool_slots, self.queue_cap,
+                                           mode, self.stream.cuda_stream), "fsq_fitq_create")
+        self.h = h
+
+    def submit(self, d_img, n_fields, H, W, d_cand, n, d_rows):
+        """-> ticket, or None when the queue has no room right now (advance and try again)."""
+        t = ctypes.c_int(-1)
+        rc = self.L.fsq_fitq_submit(self.h, d_img.data_ptr(), n_fields, H, W, d_cand.data_ptr(), int(n), d_rows.data_ptr(),
+                                    ctypes.byref(t))
+        if rc == N.FSQ_EAGAIN:
+            return None
+        N.check(rc, "fsq_fitq_submit")
+        return t.value
+
+    def advance(self, max_rounds=0, alive_below=0):
+        """-> (fits alive, batches finished during the call)."""
+        a, f = ctypes.c_int64(0), ctypes.c_int(0)
+        N.check(self.L.fsq_fitq_advance(self.h, int(max_rounds), int(alive_below), ctypes.byref(a), ctypes.byref(f)),
+                "fsq_fitq_advance")
+        return a.value, f.value
+
+    def take(self, ticket, consumer_stream):
+        """True once the batch's rows are written (consumer_stream then waits for them; the ticket is released)."""
+        rc = self.L.fsq_fitq_take(self.h, int(ticket), consumer_stream.cuda_stream)
+        if rc < 0:
+            N.check(rc, "fsq_fitq_take")
+        return rc == 1
+
+    @property
+    def alive(self):
+        return int(self.L.fsq_fitq_alive(self.h))
+
+    @property
+    def rounds(self):
+        return int(self.L.fsq_fitq_rounds(self.h))
+
+    def close(self):
+        if self.h is not None:
+            h, self.h = self.h, None
+            N.check(self.L.fsq_fitq_destroy(h), "fsq_fitq_destroy")
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+class StreamPipeline:
+    """detect -> LM fit -> consolidate over a STREAM of same-shaped batches with continuous batching of the fits.
+
+    One host thread, two HIP streams: the fit queue's rounds on one, every batch's detection, consolidation and
+    hand-over on the other.  A new batch is submitted as soon as fewer than `inject_below` fits are alive, so the
+    round launches stay full while the slow fits of earlier batches (up to 200 sequential iterations each) finish
+    inside them.  Each batch in flight needs its own candidate / row buffers (an Engine without fit workspace); the
+    detection / consolidation workspace is shared, its users all being on the side stream.  Results per batch are
+    bit-identical to Engine.run (fits are independent; only the order of execution changes).
+
+    The reference's counterpart is the image loop of pflib.image_batch / parallel_image_batch (pflib.py:940-996,
+    1082-1099)."""
+
+    def __init__(self, n_fields, H, W, depth=16, cand_per_batch=None, inject_below=None, device=None,
+                 mode=N.MODE_REF, cand_per_field=None):
+        torch = _torch()
+        self.torch = torch
+        self.dev = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
+        self.n_fields, self.H, self.W = int(n_fields), int(H), int(W)
+        self.depth = max(2, min(int(depth), N.MAX_TICKETS))
+        self.side = torch.cuda.Stream(device=self.dev)
+        self.shared_ws = torch.empty(Engine.workspace_bytes(self.n_fields, self.H, self.W), dtype=torch.uint8, device=self.dev)
+        self.engines = [Engine(self.n_fields, self.H, self.W, device=self.dev, cand_per_field=cand_per_field,
+                               fit_workspace=False, shared_ws=self.shared_ws) for _ in range(self.depth)]
+        per = int(cand_per_batch or self.engines[0].cap)
+        self.cand_per_batch = per
+        # a batch's slots are held until its last fit is done; the queue only ever holds the fits still alive
+        self.queue = FitQueue(pool_slots=min((self.depth + 2) * per, (1 << 27) - 1), queue_cap=2 * per + per // 2,
+                              mode=mode, device=self.dev)
+        self.inject_below = int(inject_below if inject_below is not None else per // 4)
+
+    def run(self, jobs, on_done=None, r2_threshold=0.7, radius=4, py2_round=True):
+        """jobs: iterable of (d_img, detect_params).  on_done(job_index, engine, total) is called, in order of
+        completion, with the side stream current and the batch consolidated on it: whatever reads the engine's
+        buffers must be enqueued on that stream inside the callback (the engine is re-used for a later job).
+        Returns the per-job candidate totals."""
+        if radius < 2:
+            raise ValueError("consolidation_radius must be at least 2")
+        torch, q = self.torch, self.queue
+        free = list(self.engines)
+        inflight, totals = {}, []
+        pending, exhausted = None, False
+        it = iter(enumerate(jobs))
+        with torch.cuda.device(self.dev), torch.cuda.stream(self.side):
+            while True:
+                if pending is None and not exhausted and free:
+                    try:
+                        j, (d_img, prm) = next(it)
+                    except StopIteration:
+                        exhausted = True
+                    else:
+                        eng = free.pop()
+                        total = eng.detect(d_img, prm)          # (synchronises the side stream: the count is needed)
+                        totals.append(total)
+                        pending = (j, eng, total, d_img)
+                if pending is not None and (not inflight or q.alive < self.inject_below):
+                    j, eng, total, d_img = pending
+                    t = q.submit(d_img, eng.n_fields, eng.H, eng.W, eng.cand, total, eng.rows)
+                    if t is not None:
+                        inflight[t] = pending
+                        pending = None
+                        continue                                 # detect the job after this one before advancing
+                    if not inflight:
+                        raise MemoryError("a batch of %d candidates does not fit the fit queue" % total)
+                if not inflight:
+                    if pending is None and exhausted:
+                        break
+                    continue
+                q.advance(0, self.inject_below if (pending is not None or not exhausted) else 0)
+                for t in sorted(inflight, key=lambda k: inflight[k][0]):
+                    if not q.take(t, self.side):
+                        continue
+                    j, eng, total, d_img = inflight.pop(t)
+                    eng.consolidate(r2_threshold, radius, py2_round)
+                    if on_done is not None:
+                        on_done(j, eng, total)
+                    free.append(eng)
+            self.side.synchronize()
+        return totals
+
+    def close(self):
+        self.queue.close()
 
 
 def fit_rois(rois, mode=N.MODE_REF):

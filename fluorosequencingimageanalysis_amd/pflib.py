@@ -70,42 +70,95 @@ def illumina_s_n(sub_img):
     return (np.amax(sub_img) - np.mean(edge)) / np.std(edge)
 
 
-def _table_to_dict(img, rows, fit):
-    """FsqRow table -> the reference's {(h, w): 12-tuple} (pflib.py:396-407, 475)."""
-    out = {}
-    for r, f in zip(rows, fit):
-        h, w = int(r["h"]), int(r["w"])
-        sub = img[h - 2:h + 3, w - 2:w + 3].astype(np.int64)
-        out[(int(r["key_h"]), int(r["key_w"]))] = (
-            np.float64(r["h0"]), np.float64(r["w0"]), np.float64(r["H"]), np.float64(r["A"]),
-            np.float64(r["sigma_h"]), np.float64(r["sigma_w"]), np.float64(r["theta"]), sub, f.copy(),
-            float(r["rmse"]), np.float64(r["r2"]), np.float64(r["s_n"]))
+def _records_to_dicts(rows, fit, sub, offs, failed=()):
+    """Peak records of a batch (engine.split_peak_records) -> one {(h, w): 12-tuple} per field, in the reference's
+    dict order (pflib.py:396-407, 475, 514-519); fields listed in `failed` give an AssertionError instance instead."""
+    cols = [rows[k].tolist() for k in ("key_h", "key_w")]
+    f64 = [[np.float64(x) for x in rows[k]] for k in ("h0", "w0", "H", "A", "sigma_h", "sigma_w", "theta")]
+    rmse = rows["rmse"].tolist()
+    r2 = [np.float64(x) for x in rows["r2"]]
+    s_n = [np.float64(x) for x in rows["s_n"]]
+    out = []
+    for f in range(len(offs) - 1):
+        if f in failed:
+            out.append(AssertionError("field %d: re-keyed peak collides with an existing key (pflib.py:518)" % f))
+            continue
+        d = {}
+        for i in range(int(offs[f]), int(offs[f + 1])):
+            d[(cols[0][i], cols[1][i])] = (f64[0][i], f64[1][i], f64[2][i], f64[3][i], f64[4][i], f64[5][i], f64[6][i],
+                                           sub[i], fit[i], rmse[i], r2[i], s_n[i])
+        out.append(d)
     return out
+
+
+def _engine_dicts(eng, d_img):
+    """Consolidated results of an Engine pass -> list of per-field dicts (AssertionError instances for failed fields)."""
+    rec, offs = eng.peak_records(d_img)
+    nkeep = eng.nkeep.cpu().numpy()
+    rows, fit, sub = _engine.split_peak_records(rec.cpu().numpy())
+    failed = set(int(f) for f in np.nonzero(nkeep[:eng.n_fields] < 0)[0])
+    return _records_to_dicts(rows, fit, sub, offs.cpu().numpy(), failed)
+
+
+#: find_peptides_batch works stacks larger than this many pixels as a stream of chunks (engine.StreamPipeline)
+MAX_PIXELS_PER_PASS = 1024 * 512 * 512
 
 
 def find_peptides_batch(images, median_filter_size=5, correlation_matrix=default_correlation_matrix,
                         candidate_pixels=None, c_std=2, r_2_threshold=0.7, consolidation_radius=4,
-                        fit_type='gauss', N_iter=10**3, engine=None):
-    """find_peptides over a stack uint16[n, H, W] in one GPU pass -> list of n dicts."""
+                        fit_type='gauss', N_iter=10**3, engine=None, errors='raise'):
+    """find_peptides over a stack uint16[n, H, W] -> list of n dicts.
+
+    One GPU pass for a stack of up to MAX_PIXELS_PER_PASS pixels; larger stacks are cut into equal chunks that are
+    streamed through engine.StreamPipeline (continuous batching of the LM fits).  errors='return' puts the
+    AssertionError of a field whose re-key collides (pflib.py:518) in that field's place instead of raising it."""
     if consolidation_radius < 2:
         raise ValueError("consolidation_radius must be at least 2")                # pflib.py:431-432
     if fit_type != 'gauss':
         raise NotImplementedError("fit_type='monte_carlo' draws from an unseeded RNG in the reference "
                                   "(pflib.py:117-177) and is not reproduced")
+    # (candidate_pixels: "Not yet implemented" in the reference, pflib.py:374 - accepted and ignored there and here)
     prm = _engine.detect_params(median_filter_size, correlation_matrix, c_std)
     imgs = _engine.as_u16_fields(images)
     if imgs.ndim != 3:
         raise ValueError("images must have shape (n, H, W)")
     n, H, W = imgs.shape
-    eng = engine or _engine.Engine(n, H, W)
-    d_img = _engine.to_device_u16(imgs)
-    total = eng.run(d_img, prm, r_2_threshold, consolidation_radius, N.MODE_REF, PY2_ROUND)
-    tables = eng.kept_tables(total)
-    out = []
-    for f, t in enumerate(tables):
-        if t is None:
-            raise AssertionError("field %d: re-keyed peak collides with an existing key (pflib.py:518)" % f)
-        out.append(_table_to_dict(imgs[f], t[0], t[1]))
+    if n == 0:
+        return []
+    per = max(1, MAX_PIXELS_PER_PASS // (H * W))
+    if engine is not None or n <= per:
+        eng = engine or _engine.Engine(n, H, W)
+        d_img = _engine.to_device_u16(imgs)
+        eng.run(d_img, prm, r_2_threshold, consolidation_radius, N.MODE_REF, PY2_ROUND)
+        out = _engine_dicts(eng, d_img)
+    else:
+        n_chunks = -(-n // per)
+        per = -(-n // n_chunks)
+        pad = n_chunks * per - n                # the last chunk is filled up with copies of the last field
+        pipe = _engine.StreamPipeline(per, H, W, depth=min(8, n_chunks + 1))
+        out = [None] * (n_chunks * per)
+        bufs = {}
+
+        def jobs():
+            for c in range(n_chunks):
+                part = imgs[c * per:(c + 1) * per]
+                if len(part) < per:
+                    part = np.concatenate([part, np.repeat(part[-1:], pad, axis=0)])
+                bufs[c] = _engine.to_device_u16(part)
+                yield bufs[c], prm
+
+        def on_done(c, eng, total):
+            out[c * per:(c + 1) * per] = _engine_dicts(eng, bufs.pop(c))
+
+        try:
+            pipe.run(jobs(), on_done, r_2_threshold, consolidation_radius, PY2_ROUND)
+        finally:
+            pipe.close()
+        out = out[:n]
+    if errors == 'raise':
+        for d in out:
+            if isinstance(d, Exception):
+                raise d
     return out
 
 
@@ -184,11 +237,33 @@ def _output_path(image_path, timestamp_epoch, output_path, suffix):
     return output_path
 
 
+class _Py2Pickler(pickle._Pickler):
+    """Protocol-0 pickler whose numpy globals carry the module paths of numpy 1.x (`numpy.core.multiarray`), which
+    numpy 2 still resolves: the files are read back by the reference's Python 2 (flexlibrary.py:541-547), whose
+    numpy has no `numpy._core`."""
+
+    def save_global(self, obj, name=None):
+        mod = getattr(obj, "__module__", None) or ""
+        if mod.startswith("numpy._core"):
+            name = name or getattr(obj, "__qualname__", None) or obj.__name__
+            self.write(pickle.GLOBAL + ("numpy.core" + mod[len("numpy._core"):]).encode("ascii") + b"\n" +
+                       name.encode("ascii") + b"\n")
+            self.memoize(obj)
+            return
+        pickle._Pickler.save_global(self, obj, name)
+
+    dispatch = dict(pickle._Pickler.dispatch)
+    import types as _types
+    dispatch[_types.FunctionType] = save_global
+    dispatch[_types.BuiltinFunctionType] = save_global
+    del _types
+
+
 def save_psfs_pkl(psfs, image_path=None, timestamp_epoch=None, output_path=None):
     """Pickle the PSF dict with protocol 0, as the reference's cPickle.dump does (pflib.py:594-636)."""
     output_path = _output_path(image_path, timestamp_epoch, output_path, '.pkl')
     with open(output_path, 'wb') as f:
-        pickle.dump(psfs, f, protocol=0)
+        _Py2Pickler(f, protocol=0).dump(psfs)
     return output_path
 
 
@@ -222,34 +297,107 @@ def read_image(image_path):
         return converted_path, np.array(im)
 
 
-def image_batch(image_paths, find_peptides_parameters=None, timestamp_epoch=None):
-    """Fit every image of a list; per-image failures are logged and skipped (pflib.py:883-996).
-    Returns {original path: (converted image path, pkl path, csv path, png path)} (png is None here)."""
-    if find_peptides_parameters is None:
-        find_peptides_parameters = {}
-    if timestamp_epoch is None:
-        timestamp_epoch = time.time()
-    out = {}
-    seen = set()
-    for p in image_paths:
-        ap = os.path.abspath(p)
-        if ap in seen:
-            continue
-        seen.add(ap)
+def save_psfs_png(psfs, image_path=None, timestamp_epoch=None, output_path=None, **kwargs):
+    """The reference draws the fitted spots over a contrast-stretched copy of the image (pflib.py:749-880).  That
+    overlay is cosmetic and outside the hot path; nothing is written and None is returned, which is
+    what image_batch's result tuple then carries in its png slot."""
+    return None
+
+
+def _fit_image_groups(images, find_peptides_parameters):
+    """find_peptides for a list of 2-D images of any shapes: same-shaped images go through the GPU together
+    (find_peptides_batch); -> list of dicts, with the exception an image raised in its place."""
+    out = [None] * len(images)
+    groups = {}
+    for i, img in enumerate(images):
         try:
-            converted, img = read_image(ap)
-            psfs = find_peptides(img, **find_peptides_parameters)
-            pkl = save_psfs_pkl(psfs, image_path=ap, timestamp_epoch=timestamp_epoch)
-            tab = save_psfs_csv(psfs, image_path=ap, timestamp_epoch=timestamp_epoch)
-            out[p] = (converted, pkl, tab, None)
-        except Exception as e:      # the reference swallows and logs every per-image failure
-            logger.exception(e, exc_info=True)
-            continue
+            a = _engine.as_u16_fields(img)
+            if a.ndim != 2:
+                raise ValueError("image must be two-dimensional")
+            groups.setdefault(a.shape, []).append((i, a))
+        except Exception as e:      # noqa: BLE001 - reported per image like the reference
+            out[i] = e
+    for shape, members in groups.items():
+        try:
+            res = find_peptides_batch(np.stack([a for _, a in members]), errors='return', **find_peptides_parameters)
+        except Exception as e:      # noqa: BLE001 - parameter errors etc. hit every image of the group
+            res = [e] * len(members)
+        for (i, _), r in zip(members, res):
+            out[i] = r
     return out
 
 
+def _candidate_counts(image_paths, detect_parameters=None):
+    """Number of PSF candidates of every image of a list (None where the image cannot be read) - what
+    pflib.parallel_image_batch balances its workers by (pflib.py:1043-1050).  Same-shaped images share a GPU pass."""
+    log = logging.getLogger()
+    prm = _engine.detect_params(**{"median_filter_size": 5, "correlation_matrix": default_correlation_matrix, "c_std": 2,
+                                   **(detect_parameters or {})})
+    out = [None] * len(image_paths)
+    groups = {}
+    for i, p in enumerate(image_paths):
+        try:
+            a = _engine.as_u16_fields(read_image(p)[1])
+            if a.ndim != 2:
+                raise ValueError("image must be two-dimensional")
+            groups.setdefault(a.shape, []).append((i, a))
+        except Exception as e:      # noqa: BLE001 - logged and skipped like pflib.py:1044-1048
+            log.exception(e, exc_info=True)
+    for (H, W), members in groups.items():
+        eng = _engine.Engine(len(members), H, W, fit_workspace=False)
+        eng.detect(_engine.to_device_u16(np.stack([a for _, a in members])), prm)
+        counts = eng.counts.cpu().numpy()
+        for k, (i, _) in enumerate(members):
+            out[i] = int(counts[k])
+    return out
+
+
+def image_batch(image_paths, find_peptides_parameters=None, timestamp_epoch=None):
+    """Find PSFs in every image of a list and save them as pickle and CSV; per-image failures are logged and
+    skipped (pflib.py:883-996).  Same-shaped images share one GPU pass.
+    Returns {absolute image path: (converted image path, pkl path, csv path, png path)} (png: save_psfs_png)."""
+    log = logging.getLogger()
+    if timestamp_epoch is None:
+        timestamp_epoch = _py2_round(time.time())
+    paths = list(dict.fromkeys(os.path.abspath(p) for p in image_paths))       # absolute, duplicates dropped (:947-949)
+    if find_peptides_parameters is None:
+        find_peptides_parameters = {}
+    read = []
+    for ap in paths:
+        try:
+            converted, img = read_image(ap)
+        except Exception as e:      # noqa: BLE001 - the reference swallows and logs every per-image failure (:960-964)
+            log.exception(e, exc_info=True)
+            continue
+        read.append((ap, converted, img))
+    results = _fit_image_groups([img for _, _, img in read], find_peptides_parameters)
+    processed = {}
+    for (ap, converted, img), psfs in zip(read, results):
+        if isinstance(psfs, Exception):
+            log.error("find_peptides failed for %s", ap, exc_info=(type(psfs), psfs, psfs.__traceback__))
+            continue
+        try:
+            pkl = save_psfs_pkl(psfs, image_path=converted, timestamp_epoch=timestamp_epoch)
+            tab = save_psfs_csv(psfs, image_path=converted, timestamp_epoch=timestamp_epoch)
+            png = save_psfs_png(psfs, image_path=converted, timestamp_epoch=timestamp_epoch)
+        except Exception as e:      # noqa: BLE001
+            log.exception(e, exc_info=True)
+            continue
+        processed.setdefault(ap, (converted, pkl, tab, png))
+    return processed
+
+
 def parallel_image_batch(image_paths, find_peptides_parameters=None, timestamp_epoch=None, num_processes=None):
-    """Same contract as pflib.parallel_image_batch (pflib.py:1000-1111).  The reference balances images
-    over worker processes; here one GPU process handles them and `num_processes` is accepted and ignored
-    (multi-GPU sharding lives in fluorosequencingimageanalysis_amd.distributed)."""
+    """Same contract as pflib.parallel_image_batch (pflib.py:1000-1111).
+
+    The reference balances the images over `num_processes` worker processes by candidate count.  Here the workers are
+    the ranks of the torch.distributed job this process belongs to (one process per GPU, `torchrun`): images are
+    balanced over them with the same longest-processing-time rule and every rank's results are merged on all ranks
+    (fluorosequencingimageanalysis_amd.distributed.image_batch_sharded).  Without a process group one GPU handles all
+    images.  num_processes is validated like the reference's (:1060-1061) and otherwise ignored."""
+    if num_processes is not None and (num_processes < 1 or round(num_processes) != num_processes):
+        raise ValueError("Number of processes must be an integer >= 1")
+    from . import distributed as _dist
+    if _dist.world_size() > 1:
+        return _dist.image_batch_sharded(image_paths, find_peptides_parameters, timestamp_epoch)
     return image_batch(image_paths, find_peptides_parameters, timestamp_epoch)

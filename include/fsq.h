@@ -31,6 +31,7 @@ extern "C" {
 #define FSQ_EHIP     (-4)   /* a HIP call failed (fsq_last_hip_error()) */
 #define FSQ_EASSERT  (-5)   /* the reference's assert at pflib.py:518 would fire */
 #define FSQ_ENOTIMPL (-6)   /* reference raises NotImplementedError (pflib.py:195) */
+#define FSQ_EAGAIN   (-7)   /* FsqFitQueue: no room for the batch right now - advance the queue and submit again */
 
 #define FSQ_MODE_REF      0 /* reference-faithful fp64 LM (qrsolv/diag(R) aliasing of mpfit.py:1915) */
 #define FSQ_MODE_TEXTBOOK 1 /* same solver with MINPACK's diagonal restore */
@@ -93,6 +94,45 @@ int64_t fsq_fit_workspace_bytes(int64_t n);
 int fsq_fit_candidates(const uint16_t* d_img, int n_fields, int H, int W, const int32_t* d_cand, int64_t n,
                        int mode, FsqRow* d_rows, void* d_workspace, int64_t workspace_bytes, void* stream);
 
+/*
+ * FsqFitQueue - the LM-fit engine kept alive ACROSS batches (continuous batching).
+ *
+ * Replaces the same reference code as fsq_fit_candidates (the candidate loop of pflib.find_peptides, pflib.py:441-477,
+ * down to mpfit); its reference-side counterpart as a whole is the image loop around that: pflib.image_batch /
+ * parallel_image_batch (pflib.py:940-996, 1082-1099), which works images one after the other (or one per process).
+ * One LM solve needs 1..200 sequential iterations, so a stand-alone batch ends in a long tail of rounds in which a
+ * few per cent of its fits are alive and the chip idles.  A queue keeps the solver state of every
+ * fit in flight in one pool: batches are submitted while earlier ones are still finishing, every round advances all of
+ * them in the same full launches, and a batch's rows are written as soon as its last fit has terminated.  Results are
+ * bit-identical to fsq_fit_candidates (fits are independent; only the order of execution changes).
+ *
+ *   pool_slots  candidates in flight at most (every batch owns n slots from submit until its rows are written;
+ *               slots are handed out in ring order, so leave room for about two batches more than are in flight)
+ *   queue_cap   fits ALIVE at most (sum over the batches in flight of their unfinished fits)
+ * The queue lives on one stream: submit / advance only enqueue on it, except that advance synchronises it every
+ * few rounds to read the queue sizes.  Not thread-safe: one host thread drives a queue.  At most FSQ_MAX_TICKETS
+ * batches in flight.
+ */
+#define FSQ_MAX_TICKETS 32
+typedef struct FsqFitQueue FsqFitQueue;
+int64_t fsq_fitq_workspace_bytes(int64_t pool_slots, int64_t queue_cap);
+int fsq_fitq_create(FsqFitQueue** q, void* d_workspace, int64_t workspace_bytes, int64_t pool_slots, int64_t queue_cap,
+                    int mode /* FSQ_MODE_REF / FSQ_MODE_TEXTBOOK */, void* stream);
+/* Add a batch (same arguments as fsq_fit_candidates; d_img / d_cand / d_rows must stay valid until the batch has been
+ * taken).  Work enqueued on the queue's stream so far must not still be writing d_cand (order it with an event or
+ * synchronise).  *ticket names the batch.  FSQ_EAGAIN: no free slots / tickets now. */
+int fsq_fitq_submit(FsqFitQueue* q, const uint16_t* d_img, int n_fields, int H, int W, const int32_t* d_cand, int64_t n,
+                    FsqRow* d_rows, int* ticket);
+/* Run rounds until at least one batch has finished, or nothing is alive, or fewer than alive_below fits are alive, or
+ * max_rounds (> 0) rounds have run.  *alive = fits still alive, *finished = batches that finished during the call. */
+int fsq_fitq_advance(FsqFitQueue* q, int64_t max_rounds, int64_t alive_below, int64_t* alive, int* finished);
+/* 1: the batch has finished - consumer_stream is made to wait for its rows, the ticket is free again;
+ * 0: still in flight; < 0: error. */
+int fsq_fitq_take(FsqFitQueue* q, int ticket, void* consumer_stream);
+int64_t fsq_fitq_alive(const FsqFitQueue* q);
+int64_t fsq_fitq_rounds(const FsqFitQueue* q);
+int fsq_fitq_destroy(FsqFitQueue* q);      /* synchronises the queue's stream */
+
 /* Fit n stand-alone ROIs uint16[n][25] (pflib._fit_2d_gaussian surface); h = w = 2, field = 0. */
 int fsq_fit_rois(const uint16_t* d_rois, int64_t n, int mode, FsqRow* d_rows, void* d_workspace,
                  int64_t workspace_bytes, void* stream);
@@ -112,6 +152,18 @@ int fsq_consolidate(FsqRow* d_rows, const int32_t* d_counts, const int32_t* d_of
                     double r2_threshold,
                     int radius, int py2_round, int32_t* d_keep, int32_t* d_nkeep, void* d_workspace,
                     int64_t workspace_bytes, void* stream);
+
+/*
+ * The kept peaks of all fields as ONE contiguous table in field order (what pflib.find_peptides returns per image,
+ * pflib.py:520, concatenated) - the unit that is gathered across GPUs and copied to the host.
+ *   d_rows / d_keep / d_offsets / d_nkeep   as fsq_consolidate leaves them
+ *   d_out          FsqRow[cap] out; rows beyond cap are dropped (d_nkeep[n_fields] is the total kept)
+ *   d_out_offsets  int32[n_fields + 1] out: field f's peaks are d_out[out_offsets[f] .. out_offsets[f+1])
+ *                  (a field whose re-key assertion fired, nkeep = -1, contributes none)
+ * Enqueue only.
+ */
+int fsq_kept_rows(const FsqRow* d_rows, const int32_t* d_keep, const int32_t* d_offsets, const int32_t* d_nkeep,
+                  int n_fields, FsqRow* d_out, int64_t cap, int32_t* d_out_offsets, void* stream);
 
 /* fit_img (double[n][25]) of rows selected by d_idx[n] (NULL = all first n rows). */
 int fsq_fit_images(const FsqRow* d_rows, const int32_t* d_idx, int64_t n, double* d_fit_img, void* stream);
