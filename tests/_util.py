@@ -12,11 +12,19 @@ FIELD_NAMES = ["f0_cfg1_512_200", "f1_cfg2_512_500", "f2_rect_384x640_300", "f3_
                "f4_dense_1024_1250", "f5_small_96"]
 
 
-def load_field(name):
-    """Returns (golden npz, image uint16) - the image is rebuilt from its seed and CRC-checked."""
-    g = np.load(os.path.join(GOLD, "field_%s.npz" % name))
+DEGEN_NAMES = ["d0_flat_32", "d1_sat_40", "d2_satpart_48", "d3_dim_48", "d4_noise_40", "d5_noise_lo_36",
+               "d6_hotpixel_32", "d7_zero_24"]
+TEXTBOOK_NAMES = ["f5_small_96", "f3_hard_256"]
+
+
+def load_field(name, prefix="field_"):
+    """Returns (golden npz, image uint16) - the image is rebuilt from its seed (or taken from the fixture when it
+    is stored there: the degenerate frames) and CRC-checked."""
+    g = np.load(os.path.join(GOLD, "%s%s.npz" % (prefix, name)))
     shape = tuple(int(x) for x in g["shape"])
-    if str(g["kind"]) == "hard":
+    if str(g["kind"]) == "image":
+        img = g["image"]
+    elif str(g["kind"]) == "hard":
         img = synth.make_hard_field(int(g["seed"]), shape, int(g["n_spots"]))
     else:
         img = synth.make_field(int(g["seed"]), shape, int(g["n_spots"]))

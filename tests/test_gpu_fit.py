@@ -4,7 +4,7 @@ exit status, iteration and evaluation counts, and the fit-quality metrics."""
 import numpy as np
 import pytest
 
-from _util import FIELD_NAMES, bits_equal, load_field, rois_of
+from _util import DEGEN_NAMES, FIELD_NAMES, TEXTBOOK_NAMES, bits_equal, load_field, rois_of
 
 pytestmark = pytest.mark.gpu
 
@@ -67,6 +67,43 @@ def test_lane_engine_equals_quad_engine(env, name):
     b = gpu_fit_rois(torch, N, rois, mode=0 | N.ENGINE_LANE)
     c = gpu_fit_rois(torch, N, rois, mode=0 | N.ENGINE_QUAD)
     assert a.tobytes() == b.tobytes() == c.tobytes()
+
+
+def _rows_equal_golden(got, g):
+    p = np.stack([got[k] for k in ("H", "A", "p2", "p3", "sigma_h", "sigma_w", "theta")], axis=1)
+    assert bits_equal(p, g["params"]).all()
+    for k in ("status", "niter"):
+        assert np.array_equal(got[k], g[k]), k
+    assert np.array_equal(got["nfev"], g["nfev"])
+
+
+@pytest.mark.parametrize("name", DEGEN_NAMES)
+def test_degenerate_frames_equal_reference(env, name):
+    """Flat / saturated / dim / pure-noise / hot-pixel / all-zero frames: every LM solve (incl. the gtol exits, status 4,
+    and the zero-variance ROIs) and the whole find_peptides table equal the reference's recorded output
+    (tests/golden/degen_*.npz, oracle/gen_golden.py --only degen)."""
+    torch, N, O = env
+    from fluorosequencingimageanalysis_amd import pflib
+    g, img = load_field(name, prefix="degen_")
+    assert pflib._psf_candidates(img) == [tuple(int(v) for v in hw) for hw in g["candidates"]]
+    _rows_equal_golden(gpu_fit_rois(torch, N, rois_of(img, g["candidates"])), g)
+    d = pflib.find_peptides(img)
+    assert np.array_equal(np.array(list(d.keys()), dtype=np.int32).reshape(-1, 2), g["table_keys"].reshape(-1, 2))
+    vals = list(d.values())
+    got7 = np.array([[float(x) for x in v[:7]] for v in vals]).reshape(-1, 7)
+    assert bits_equal(got7, g["table7"].reshape(-1, 7)).all()
+    gotm = np.array([[float(v[9]), float(v[10]), float(v[11])] for v in vals]).reshape(-1, 3)
+    assert bits_equal(gotm, g["table_metrics"].reshape(-1, 3)).all()           # NaN r_2 / s_n included
+    if len(vals):
+        assert bits_equal(np.array([v[8] for v in vals]).reshape(-1, 5, 5), g["table_fit"]).all()
+
+
+@pytest.mark.parametrize("name", TEXTBOOK_NAMES)
+def test_textbook_mode_equals_patched_reference(env, name):
+    """FSQ_MODE_TEXTBOOK == the reference run with MINPACK's qrsolv (tests/golden/textbook_*.npz)."""
+    torch, N, O = env
+    g, img = load_field(name, prefix="textbook_")
+    _rows_equal_golden(gpu_fit_rois(torch, N, rois_of(img, g["candidates"]), mode=1), g)
 
 
 def test_textbook_mode(env):

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import oracle as O
-from _util import FIELD_NAMES, GOLD, bits_equal, load_field, rois_of
+from _util import DEGEN_NAMES, FIELD_NAMES, GOLD, TEXTBOOK_NAMES, bits_equal, load_field, rois_of
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -52,6 +52,53 @@ def test_find_peptides_table(name):
     assert np.array_equal(sub, g["table_sub"])
     fit = np.stack([O.model(p) for p in fits["p"][keep]])
     assert bits_equal(fit, g["table_fit"]).all()
+
+
+def _check_against_golden(g, img, mode):
+    """candidates, every LM solve and the consolidated table of one fixture, bit for bit."""
+    assert np.array_equal(O.candidates(img), g["candidates"])
+    f = O.fit_rois(rois_of(img, g["candidates"]), mode=mode, n_threads=os.cpu_count())
+    assert bits_equal(f["p"], g["params"]).all()
+    for k in ("status", "niter", "nfev"):
+        assert np.array_equal(f[k], g[k]), k
+    assert bits_equal(f["fnorm"], g["fnorm"]).all()
+    if int(g["table_error"]):
+        with pytest.raises(AssertionError):
+            O.find_peptides(img, mode=mode, n_threads=os.cpu_count())
+        return
+    rows, fits, keep, key = O.find_peptides(img, mode=mode, n_threads=os.cpu_count())
+    assert np.array_equal(key, g["table_keys"].reshape(-1, 2))
+    r = rows[keep]
+    got7 = np.stack([r[k] for k in ("h0", "w0", "H", "A", "sigma_h", "sigma_w", "theta")], axis=1)
+    assert bits_equal(got7, g["table7"].reshape(-1, 7)).all()
+    gotm = np.stack([r["rmse"], r["r2"], r["s_n"]], axis=1)
+    assert bits_equal(gotm, g["table_metrics"].reshape(-1, 3)).all()      # (bits_equal treats NaN == NaN)
+
+
+@pytest.mark.parametrize("name", DEGEN_NAMES)
+def test_degenerate_frames_match_reference(name):
+    """Flat, saturated, dim, pure-noise, hot-pixel and all-zero frames through the unmodified reference
+    (oracle/gen_golden.py --only degen): gtol exits (status 4, mpfit.py:1151), zero-variance ROIs whose r_2 is NaN
+    and passes the filter (pflib.py:466), consolidation among NaN scores.  (mpfit's status-0 early returns,
+    mpfit.py:956-964, cannot be reached through pflib: gaussfitter clips the start into the bounds, gaussfitter.py:202-204;
+    none of these frames drives a step non-finite, status -16, mpfit.py:1330-1335.)"""
+    g, img = load_field(name, prefix="degen_")
+    _check_against_golden(g, img, mode=0)
+
+
+def test_degenerate_goldens_cover_the_cases():
+    st = np.concatenate([np.load(os.path.join(GOLD, "degen_%s.npz" % n))["status"] for n in DEGEN_NAMES])
+    assert (st == 4).any() and (st == 2).any() and (st == 5).any()
+    m = np.load(os.path.join(GOLD, "degen_d7_zero_24.npz"))["table_metrics"]
+    assert np.isnan(m[:, 1]).any()                      # a kept peak whose r_2 is NaN
+
+
+@pytest.mark.parametrize("name", TEXTBOOK_NAMES)
+def test_textbook_mode_matches_patched_reference(name):
+    """mode=1 == the reference run with MINPACK's qrsolv (the solution vector a COPY of R's diagonal,
+    refload.load_reference(textbook_qrsolv=True)): pins FSQ_MODE_TEXTBOOK."""
+    g, img = load_field(name, prefix="textbook_")
+    _check_against_golden(g, img, mode=1)
 
 
 def test_textbook_mode_differs_but_converges():
