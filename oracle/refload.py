@@ -77,7 +77,9 @@ def load_reference(textbook_qrsolv=False):
     libm = ctypes.CDLL("libm.so.6")
     libm.round.restype = ctypes.c_double
     libm.round.argtypes = [ctypes.c_double]
-    pf = load("pflib", "pflib.py", inject={"round": lambda x: libm.round(float(x))})
+    # (Python 3: pickle.dump needs a binary file - the reference opens it in Python 2's text mode 'w', pflib.py:635)
+    pf = load("pflib", "pflib.py", [("pickle.dump(psfs, open(output_path, 'w'))", "pickle.dump(psfs, open(output_path, 'wb'))")],
+              inject={"round": lambda x: libm.round(float(x))})
     pc = load("phase_correlate", "phase_correlate.py",
               [("np.array(ref_image, dtype=np.float64, copy=False)",
                 "np.asarray(ref_image, dtype=np.float64)"),

@@ -1,0 +1,192 @@
+"""CPU tests of the batch / IO / CLI layer around the hot path (SURVEY.md 8a rows image_batch, output formats; 8f N2):
+pflib.read_image, save_psfs_csv / save_psfs_pkl / _psfs_filename against files the REFERENCE wrote
+(tests/golden/io_f5_small_96*, oracle/gen_golden.py --only io), image_batch's path / grouping / swallow-and-log
+semantics (pflib.py:940-996) and the basic_image_script command line (basic_image_script.py:36-124).
+The GPU work is stood in for by the reference's recorded table where a test needs PSFs - the compute path itself is
+covered by the -m gpu tests (tests/test_gpu_batch_io.py runs this layer on the real thing)."""
+import json
+import logging
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from _util import GOLD, load_field
+
+
+def golden_psfs(name="f5_small_96"):
+    """The reference's find_peptides dict for a golden field, rebuilt from the fixture."""
+    g, img = load_field(name)
+    d = {}
+    for k, t7, sub, fit, m in zip(g["table_keys"], g["table7"], g["table_sub"], g["table_fit"], g["table_metrics"]):
+        d[(int(k[0]), int(k[1]))] = tuple(np.float64(x) for x in t7) + (sub, fit, float(m[0]), np.float64(m[1]), np.float64(m[2]))
+    return d, img
+
+
+def test_csv_equals_reference_file(tmp_path):
+    """save_psfs_csv against the file the reference's save_psfs_csv wrote for the same PSFs (pflib.py:639-711):
+    same name, header, path column, row order and line ends; every number equal to the 12 significant digits
+    Python 2's str() printed (the fixture was written under Python 3, which prints 17)."""
+    from fluorosequencingimageanalysis_amd import pflib
+    meta = json.load(open(os.path.join(GOLD, "io_f5_small_96.json")))
+    ref_text = open(os.path.join(GOLD, "io_f5_small_96_psfs.csv"), newline="").read().replace("<DIR>", str(tmp_path))
+    psfs, _ = golden_psfs()
+    assert [list(k) for k in psfs] == meta["keys"]
+    image = meta["image"].replace("<DIR>", str(tmp_path))
+    os.makedirs(os.path.dirname(image))
+    path = pflib.save_psfs_csv(psfs, image_path=image, timestamp_epoch=meta["epoch"])
+    assert path == meta["csv_path"].replace("<DIR>", str(tmp_path))
+    got = open(path, newline="").read()
+    assert got.count("\r\n") == ref_text.count("\r\n") == len(psfs) + 1            # excel-tab dialect line ends
+    gl, rl = got.split("\r\n"), ref_text.split("\r\n")
+    assert gl[0] == rl[0]
+    for a, b in zip(gl[1:-1], rl[1:-1]):
+        fa, fb = a.split("\t"), b.split("\t")
+        assert fa[0] == fb[0] == image and len(fa) == len(fb) == 11
+        for x, y in zip(fa[1:], fb[1:]):
+            assert x == pflib._py2_str(float(y))
+            assert abs(float(x) - float(y)) <= 1e-11 * abs(float(y))
+    assert pflib.save_psfs_pkl(psfs, image_path=image, timestamp_epoch=meta["epoch"]) == meta["pkl_path"].replace("<DIR>", str(tmp_path))
+    for p, e, sfx, exp in meta["filename_kat"]:
+        assert pflib._psfs_filename(p, e, sfx) == exp
+
+
+def test_pkl_round_trip_and_py2_module_paths(tmp_path):
+    """save_psfs_pkl: protocol 0 like cPickle.dump's default (pflib.py:635); what is read back equals the dict; the
+    stream names numpy's globals by their numpy-1 paths (the reference's Python 2 reads these files,
+    flexlibrary.py:541-547).  Interop with a real Python 2 cannot be run here: parity unpinned for that."""
+    from fluorosequencingimageanalysis_amd import pflib
+    psfs, _ = golden_psfs()
+    p = pflib.save_psfs_pkl(psfs, output_path=str(tmp_path / "x.pkl"))
+    raw = open(p, "rb").read()
+    assert raw.startswith(b"(dp") and b"numpy._core" not in raw and b"numpy.core.multiarray" in raw
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        back = pickle.load(open(p, "rb"))
+    assert list(back.keys()) == list(psfs.keys())
+    for k in psfs:
+        for a, b in zip(back[k], psfs[k]):
+            assert np.array_equal(np.asarray(a), np.asarray(b)) and type(a) is type(b)
+    with pytest.raises(ValueError):
+        pflib.save_psfs_pkl(psfs)
+
+
+def _write_tif(path, arr):
+    from PIL import Image
+    Image.fromarray(arr).save(path, format="TIFF")
+
+
+def test_read_image_16bit(tmp_path):
+    from PIL import Image
+    from fluorosequencingimageanalysis_amd import pflib
+    _, img = load_field("f5_small_96")
+    _write_tif(str(tmp_path / "a.tif"), img)
+    conv, arr = pflib.read_image(str(tmp_path / "a.tif"))
+    assert conv == str(tmp_path / "a.tif") and arr.dtype == np.uint16 and np.array_equal(arr, img)
+    # an existing '<image>.png' is what the reference reads instead (pflib.py:737-739)
+    Image.fromarray((img // 2).astype(np.uint16)).save(str(tmp_path / "a.tif.png"))
+    conv, arr = pflib.read_image(str(tmp_path / "a.tif"))
+    assert conv == str(tmp_path / "a.tif.png") and np.array_equal(arr, img // 2)
+    with pytest.raises(Exception):
+        pflib.read_image(str(tmp_path / "missing.tif"))
+
+
+@pytest.fixture
+def fake_gpu(monkeypatch):
+    """find_peptides_batch stood in for: every field 'finds' the golden PSFs (records what it was called with)."""
+    from fluorosequencingimageanalysis_amd import pflib
+    psfs, _ = golden_psfs()
+    calls = []
+
+    def fake(images, errors='raise', **kw):
+        calls.append((np.asarray(images).shape, kw))
+        if kw.get("fit_type", "gauss") != "gauss":
+            raise NotImplementedError("monte_carlo")
+        out = []
+        for im in images:
+            out.append(AssertionError("re-key") if int(im[0, 0]) == 7 else dict(psfs))
+        return out
+    monkeypatch.setattr(pflib, "find_peptides_batch", fake)
+    return calls
+
+
+def test_image_batch_semantics(tmp_path, fake_gpu, monkeypatch, caplog):
+    """pflib.image_batch (pflib.py:940-996): absolute de-duplicated keys, output names derived from the CONVERTED path,
+    unreadable / failing images logged and skipped, same-shaped images in one GPU call."""
+    from PIL import Image
+    from fluorosequencingimageanalysis_amd import pflib
+    _, img = load_field("f5_small_96")
+    d = tmp_path / "run"
+    d.mkdir()
+    _write_tif(str(d / "a.tif"), img)
+    _write_tif(str(d / "b.tif"), img)
+    _write_tif(str(d / "c.tif"), img[:64, :80].copy())
+    bad = img.copy()
+    bad[0, 0] = 7                                       # the stand-in raises the re-key assertion for this one
+    _write_tif(str(d / "d.tif"), bad)
+    (d / "corrupt.tif").write_bytes(b"not an image")
+    Image.fromarray(img).save(str(d / "b.tif.png"))     # b has a converted sibling
+    monkeypatch.chdir(d)
+    with caplog.at_level(logging.ERROR):
+        res = pflib.image_batch(["a.tif", str(d / "a.tif"), "b.tif", "c.tif", "d.tif", "corrupt.tif", "nope.tif"],
+                                find_peptides_parameters={"c_std": 3}, timestamp_epoch=1450000000.4)
+    assert sorted(res) == [str(d / "a.tif"), str(d / "b.tif"), str(d / "c.tif")]
+    conv, pkl, tab, png = res[str(d / "b.tif")]
+    assert conv == str(d / "b.tif.png") and pkl == conv + "_psfs_nzaj5s.pkl" and tab == conv + "_psfs_nzaj5s.csv" and png is None
+    assert res[str(d / "a.tif")][1] == str(d / "a.tif") + "_psfs_nzaj5s.pkl"
+    for v in res.values():
+        assert os.path.exists(v[1]) and os.path.exists(v[2])
+        assert open(v[2]).read().splitlines()[1].split("\t")[0] == v[0]          # 'Absolute image path' = converted path
+    shapes = sorted(c[0] for c in fake_gpu)
+    assert shapes == [(1, 64, 80), (3, 96, 96)] and all(c[1] == {"c_std": 3} for c in fake_gpu)
+    assert len([r for r in caplog.records if r.levelno >= logging.ERROR]) == 3   # corrupt, missing, re-key
+
+
+def test_parallel_image_batch_validates_num_processes(fake_gpu, tmp_path):
+    from fluorosequencingimageanalysis_amd import pflib
+    _, img = load_field("f5_small_96")
+    _write_tif(str(tmp_path / "a.tif"), img)
+    with pytest.raises(ValueError):
+        pflib.parallel_image_batch([str(tmp_path / "a.tif")], num_processes=0)           # pflib.py:1060-1061
+    with pytest.raises(ValueError):
+        pflib.parallel_image_batch([str(tmp_path / "a.tif")], num_processes=2.5)
+    res = pflib.parallel_image_batch([str(tmp_path / "a.tif")], num_processes=4, timestamp_epoch=36)
+    assert list(res) == [str(tmp_path / "a.tif")] and res[str(tmp_path / "a.tif")][1].endswith("_psfs_10.pkl")
+
+
+def test_basic_image_script_cli(tmp_path, fake_gpu, monkeypatch):
+    """basic_image_script.py:84-124: --parameters through ast.literal_eval, -mc fills fit_type / N_iter without
+    overriding, *.tif files of every directory tree, the log file, the call into parallel_image_batch."""
+    from fluorosequencingimageanalysis_amd import basic_image_script as cli, pflib
+    _, img = load_field("f5_small_96")
+    (tmp_path / "p1" / "deep").mkdir(parents=True)
+    (tmp_path / "p2").mkdir()
+    _write_tif(str(tmp_path / "p1" / "x.tif"), img)
+    _write_tif(str(tmp_path / "p1" / "deep" / "y.tif"), img)
+    _write_tif(str(tmp_path / "p2" / "z.tif"), img)
+    (tmp_path / "p2" / "skip.tiff").write_bytes(b"")
+    (tmp_path / "p2" / "note.txt").write_text("x")
+    seen = {}
+    real = pflib.parallel_image_batch
+
+    def spy(paths, find_peptides_parameters=None, timestamp_epoch=None, num_processes=None):
+        seen.update(paths=list(paths), fp=find_peptides_parameters, n=num_processes, t=timestamp_epoch)
+        return real(paths, find_peptides_parameters, timestamp_epoch, num_processes)
+    monkeypatch.setattr(pflib, "parallel_image_batch", spy)
+    log = str(tmp_path / "run.log")
+    out = cli.main(["--parameters", "{'median_filter_size': 7, 'c_std': 3}", "-n", "3", "-L", log,
+                    str(tmp_path / "p1"), str(tmp_path / "p2")])
+    assert sorted(seen["paths"]) == sorted(str(tmp_path / p) for p in ("p1/x.tif", "p1/deep/y.tif", "p2/z.tif"))
+    assert seen["fp"] == {"median_filter_size": 7, "c_std": 3} and seen["n"] == 3 and isinstance(seen["t"], float)
+    assert sorted(out) == sorted(seen["paths"])
+    text = open(log).read()
+    assert "basic_image_script starting at" in text and "Will process target images" in text and "x.tif" in text
+    # -mc: fit_type / N_iter only where --parameters did not set them; the GPU path refuses monte_carlo per image
+    out = cli.main(["-mc", "--N_iter", "50", "--parameters", "{'N_iter': 9}", "-L", log, str(tmp_path / "p2")])
+    assert seen["fp"] == {"N_iter": 9, "fit_type": "monte_carlo"} and out == {}
+    with pytest.raises(SystemExit):
+        cli.main(["-L", log])                           # at least one directory
+    with pytest.raises((ValueError, SyntaxError)):
+        cli.main(["--parameters", "{'c_std': ", "-L", log, str(tmp_path / "p2")])
