@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("FSQ_HIP_LIB") or os.path.join(HERE, "csrc", "libfsq_h
 FSQ_OK, FSQ_EINVAL, FSQ_ENOMEM, FSQ_ERANGE, FSQ_EHIP, FSQ_EASSERT, FSQ_ENOTIMPL, FSQ_EAGAIN = 0, -1, -2, -3, -4, -5, -6, -7
 MAX_TICKETS = 32
 MODE_REF, MODE_TEXTBOOK, ENGINE_LANE, ENGINE_QUAD = 0, 1, 0x100, 0x200
+PIXELS_U16, PIXELS_F16, PIXELS_F16_FLAG = 0, 1, 0x1000
 
 ROW_DTYPE = np.dtype([(k, np.float64) for k in
                       ("h0", "w0", "H", "A", "sigma_h", "sigma_w", "theta", "rmse", "r2", "s_n", "p2", "p3")] +
@@ -22,7 +23,7 @@ assert ROW_DTYPE.itemsize == 128
 
 class FsqDetectParams(ctypes.Structure):
     _fields_ = [("median_filter_size", ctypes.c_int32), ("ksz", ctypes.c_int32), ("c_std", ctypes.c_double),
-                ("K", ctypes.c_int64 * 81)]
+                ("K", ctypes.c_int64 * 81), ("pixel_format", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class NativeLibraryMissing(RuntimeError):
@@ -46,7 +47,7 @@ _SIGS = {
     "fsq_fitq_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64, ctypes.c_int64]),
     "fsq_fitq_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                        ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
-    "fsq_fitq_submit": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+    "fsq_fitq_submit": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]),
     "fsq_fitq_advance": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64),
                                         ctypes.POINTER(ctypes.c_int)]),

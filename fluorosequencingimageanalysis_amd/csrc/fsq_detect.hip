@@ -99,7 +99,7 @@ __device__ int median_generic(const unsigned short* raw, int pitch, int r0, int 
 // ---------------------------------------------------------------------------------------------
 // K1. grid = (ceil(W/TW), ceil(H/TH), n_fields), block = 256.
 template <bool FAST5>
-__global__ void __launch_bounds__(256) k1_response(const uint16_t* __restrict__ img, int H, int W, DetectConst dc,
+__global__ void __launch_bounds__(256) k1_response(const uint16_t* __restrict__ img, int pix_fmt, int H, int W, DetectConst dc,
                                                    long long* __restrict__ cm, unsigned long long* __restrict__ field_sum)
 {
     extern __shared__ unsigned char smem[];
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) k1_response(const uint16_t* __restrict__ 
     for (int i = tid; i < RH * RW; i += 256) {       // raw tile with 'reflect' indexing
         int rr = i / RW, cc = i - rr * RW;
         int gh = reflect_idx(h0 - kc - mo + rr, H), gw = reflect_idx(w0 - kc - mo + cc, W);
-        raw[i] = im[(size_t)gh * W + gw];
+        raw[i] = (unsigned short)fsq_pixel(im, (size_t)gh * W + gw, pix_fmt);
     }
     __syncthreads();
     for (int i = tid; i < MH * MW; i += 256) {       // mf = img - min(median, img); 0 outside the image
@@ -416,6 +416,7 @@ extern "C" int fsq_detect(const uint16_t* d_img, int n_fields, int H, int W, con
     if (!prm) return FSQ_EINVAL;
     const int med = prm->median_filter_size, ksz = prm->ksz;
     if (ksz < 1 || (ksz % 2) == 0) return FSQ_EINVAL;                 // pflib.py:236-239 -> ValueError
+    if (prm->pixel_format != FSQ_PIXELS_U16 && prm->pixel_format != FSQ_PIXELS_F16) return FSQ_EINVAL;
     if (ksz > MAXK || med < 1 || med > MAXK) return FSQ_ENOTIMPL;
     if (n_fields < 1 || H < 1 || W < 1 || cap < 0 || !d_img || !d_counts || !d_offsets || !d_workspace) return FSQ_EINVAL;
     if (cap > 0 && !d_cand) return FSQ_EINVAL;
@@ -451,8 +452,8 @@ extern "C" int fsq_detect(const uint16_t* d_img, int n_fields, int H, int W, con
         const int MH = TH + 2 * kc, MW = TW + 2 * kc, RH = MH + mo + me, RW = MW + mo + me;
         size_t shm = (((size_t)RH * RW * 2 + 15) & ~(size_t)15) + (size_t)MH * MW * 4;
         dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, n_fields);
-        if (med == 5) hipLaunchKernelGGL(k1_response<true>, grid, dim3(256), shm, s, d_img, H, W, dc, cm, field_sum);
-        else hipLaunchKernelGGL(k1_response<false>, grid, dim3(256), shm, s, d_img, H, W, dc, cm, field_sum);
+        if (med == 5) hipLaunchKernelGGL(k1_response<true>, grid, dim3(256), shm, s, d_img, prm->pixel_format, H, W, dc, cm, field_sum);
+        else hipLaunchKernelGGL(k1_response<false>, grid, dim3(256), shm, s, d_img, prm->pixel_format, H, W, dc, cm, field_sum);
     }
     hipLaunchKernelGGL(k2_sqdev_chunks, dim3(n_chunks, n_fields), dim3(256), 0, s, cm, N, field_sum, n_chunks, chunk_sum);
     hipLaunchKernelGGL(k2_threshold, dim3((n_fields + 63) / 64), dim3(64), 0, s, field_sum, chunk_sum, n_chunks, N,

@@ -161,6 +161,9 @@ extern "C" int fsq_fit_candidates(const uint16_t* d_img, int n_fields, int H, in
     if (n < 0 || H < 5 || W < 5 || n_fields < 1 || (m != FSQ_MODE_REF && m != FSQ_MODE_TEXTBOOK)) return FSQ_EINVAL;
     if (n == 0) return FSQ_OK;
     if (!d_img || !d_cand || !d_rows) return FSQ_EINVAL;
+    if ((mode & FSQ_PIXELS_F16_FLAG) && (mode & (FSQ_ENGINE_LANE | FSQ_ENGINE_QUAD))) return FSQ_ENOTIMPL;   // A/B engines: uint16 only
+    if (mode & FSQ_PIXELS_F16_FLAG)
+        return fsq_launch_fit_rounds(d_img, H, W, d_cand, n, m | FSQ_PIXELS_F16_FLAG, true, d_rows, d_workspace, workspace_bytes, (hipStream_t)stream);
     if (mode & FSQ_ENGINE_LANE) return fsq_launch_fit(d_img, H, W, d_cand, n, m, true, d_rows, (hipStream_t)stream);
     if (mode & FSQ_ENGINE_QUAD) return fsq_launch_fit_quad(d_img, H, W, d_cand, n, m, true, d_rows, d_workspace, workspace_bytes, (hipStream_t)stream);
     return fsq_launch_fit_rounds(d_img, H, W, d_cand, n, m, true, d_rows, d_workspace, workspace_bytes, (hipStream_t)stream);

@@ -103,6 +103,7 @@ FSQ_DEV int wave_reserve(int* counter, bool want)
 // One batch of candidates: where its pixels come from, which pool slots it owns, where its rows go.
 struct BatchArgs {
     const uint16_t* src; const int32_t* cand; int H, W; long long n; int from_image;
+    int pix_fmt;              // FSQ_PIXELS_U16 / FSQ_PIXELS_F16 (images only; stand-alone ROIs are uint16)
     long long base;           // first pool slot
     int ticket;
 };
@@ -136,7 +137,7 @@ FSQ_DEV void roi_pixels(const BatchArgs& c, long long idx, double* d)
 #pragma unroll
         for (int a = 0; a < 5; a++)
 #pragma unroll
-            for (int b = 0; b < 5; b++) d[a * 5 + b] = (double)base[(size_t)a * c.W + b];
+            for (int b = 0; b < 5; b++) d[a * 5 + b] = (double)fsq_pixel(base, (size_t)a * c.W + b, c.pix_fmt);
     } else {
 #pragma unroll
         for (int k = 0; k < FSQ_NPIX; k++) d[k] = (double)c.src[idx * FSQ_NPIX + k];
@@ -1212,9 +1213,10 @@ struct FsqFitQueue {
         return -1;
     }
 
-    int submit(const uint16_t* src, int H, int W, const int32_t* cand, long long n, bool from_image, FsqRow* rows, int* ticket)
+    int submit(const uint16_t* src, int pix_fmt, int H, int W, const int32_t* cand, long long n, bool from_image, FsqRow* rows, int* ticket)
     {
         if (n < 0 || (n > 0 && (!src || !rows || (from_image && !cand)))) return FSQ_EINVAL;
+        if (pix_fmt != FSQ_PIXELS_U16 && pix_fmt != FSQ_PIXELS_F16) return FSQ_EINVAL;
         int t = -1;
         for (int k = 0; k < FSQ_MAX_TICKETS; k++)
             if (b[k].state == T_FREE) { t = k; break; }
@@ -1223,7 +1225,7 @@ struct FsqFitQueue {
         const long long base = n > 0 ? alloc_slots(n) : 0;
         if (base < 0) return FSQ_EAGAIN;
         Batch& B = b[t];
-        B.a.src = src; B.a.cand = cand; B.a.H = H; B.a.W = W; B.a.n = n; B.a.from_image = from_image ? 1 : 0;
+        B.a.src = src; B.a.cand = cand; B.a.H = H; B.a.W = W; B.a.n = n; B.a.from_image = from_image ? 1 : 0; B.a.pix_fmt = pix_fmt;
         B.a.base = base; B.a.ticket = t; B.rows = rows;
         if (!single_call && !B.ev) FSQ_HIP_CHECK(hipEventCreateWithFlags(&B.ev, hipEventDisableTiming));
         if (n == 0) {
@@ -1375,7 +1377,7 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
     FsqFitQueue q;
     int rc = q.init(d_ws, ws_bytes, (size_t)n + 64, (size_t)n + 64, mode, s_user, true);
     if (rc != FSQ_OK) return rc;
-    rc = q.submit(d_src, H, W, d_cand, n, from_image, d_rows, nullptr);
+    rc = q.submit(d_src, (mode & FSQ_PIXELS_F16_FLAG) ? FSQ_PIXELS_F16 : FSQ_PIXELS_U16, H, W, d_cand, n, from_image, d_rows, nullptr);
     if (rc != FSQ_OK) return rc;
     while (q.alive > 0) {
         rc = q.advance(q.cfg.max_rounds, 0, nullptr, nullptr);
@@ -1409,11 +1411,11 @@ extern "C" int fsq_fitq_create(FsqFitQueue** out, void* d_workspace, int64_t wor
     return FSQ_OK;
 }
 
-extern "C" int fsq_fitq_submit(FsqFitQueue* q, const uint16_t* d_img, int n_fields, int H, int W, const int32_t* d_cand,
-                               int64_t n, FsqRow* d_rows, int* ticket)
+extern "C" int fsq_fitq_submit(FsqFitQueue* q, const void* d_img, int pixel_format, int n_fields, int H, int W,
+                               const int32_t* d_cand, int64_t n, FsqRow* d_rows, int* ticket)
 {
     if (!q || n_fields < 0 || H < 5 || W < 5) return FSQ_EINVAL;
-    return q->submit(d_img, H, W, d_cand, n, true, d_rows, ticket);
+    return q->submit((const uint16_t*)d_img, pixel_format, H, W, d_cand, n, true, d_rows, ticket);
 }
 
 extern "C" int fsq_fitq_advance(FsqFitQueue* q, int64_t max_rounds, int64_t alive_below, int64_t* alive, int* finished)

@@ -132,7 +132,7 @@ def find_peptides_sharded(images, partition="lpt", dst=0, **find_peptides_parame
     world, rank = world_size(), get_rank()
     if world == 1:
         return pflib.find_peptides_batch(images, **find_peptides_parameters)
-    imgs = E.as_u16_fields(images)
+    imgs, fmt = E.as_pixel_fields(images)
     if imgs.ndim != 3:
         raise ValueError("images must have shape (n, H, W)")
     n, H, W = imgs.shape
@@ -143,7 +143,7 @@ def find_peptides_sharded(images, partition="lpt", dst=0, **find_peptides_parame
     if fp.get("fit_type", "gauss") != "gauss":
         raise NotImplementedError("fit_type='monte_carlo' is not reproduced (pflib.py:117-177)")
     prm = E.detect_params(fp.get("median_filter_size", 5), fp.get("correlation_matrix", pflib.default_correlation_matrix),
-                          fp.get("c_std", 2))
+                          fp.get("c_std", 2), fmt)
     dev = torch.device("cuda", torch.cuda.current_device())
 
     def run_share(idx, fit):
@@ -183,7 +183,7 @@ def find_peptides_sharded(images, partition="lpt", dst=0, **find_peptides_parame
     fields, _ = gather_tables(per_field.contiguous(), dst)
     if rank != dst:
         return None
-    rows, fit, sub = E.split_peak_records(table.cpu().numpy())
+    rows, fit, sub = E.split_peak_records(table.cpu().numpy(), fmt)
     nk = fields.cpu().numpy().reshape(-1)
     order = [i for p in parts for i in p]                  # global field index of every gathered per-field entry
     failed = set(int(k) for k in np.nonzero(nk < 0)[0])

@@ -23,7 +23,8 @@ def _torch():
 
 
 def to_device_u16(images, device=None):
-    """uint16 numpy array (any shape) -> int16-typed torch tensor on the GPU holding the same bytes."""
+    """uint16 numpy array (any shape; or the 16-bit words of a float16 image, as_pixel_fields) -> int16-typed torch
+    tensor on the GPU holding the same bytes."""
     torch = _torch()
     a = np.ascontiguousarray(images, dtype=np.uint16)
     return torch.from_numpy(a.view(np.int16)).to(device or "cuda", non_blocking=False)
@@ -41,7 +42,36 @@ def as_u16_fields(image):
     return np.ascontiguousarray(a.astype(np.uint16))
 
 
-def detect_params(median_filter_size, correlation_matrix, c_std):
+def as_pixel_fields(image):
+    """-> (16-bit words to upload, pixel format).  Integer images are validated like as_u16_fields; a float16 image
+    (BASELINE.json configs[4]: pixel values pre-scaled into binary16) is uploaded as it is and truncated toward zero
+    by the kernels' loads, which is what the reference's image.astype(np.int64) (pflib.py:241, 443) does with it."""
+    a = np.asarray(image)
+    if a.dtype == np.float16:
+        if a.size and not (np.isfinite(a).all() and (a >= 0).all()):
+            raise NotImplementedError("float16 pixels must be finite and non-negative")
+        return np.ascontiguousarray(a).view(np.uint16), N.PIXELS_F16
+    return as_u16_fields(a), N.PIXELS_U16
+
+
+def quantise_f16(images):
+    """Integer pixels -> (float16 image, scale): scaled down just enough to fit binary16's range (max 65504), then
+    rounded to binary16 ("image pre-scaled to fit fp16")."""
+    a = np.asarray(images)
+    mx = float(a.max()) if a.size else 0.0
+    scale = 1.0 if mx <= 65504.0 else 65504.0 / mx
+    return (a.astype(np.float64) * scale).astype(np.float16), scale
+
+
+def pixel_values(words, pixel_format):
+    """The integer pixel values the kernels see for 16-bit words of the given format (host side, for sub_img)."""
+    w = np.asarray(words)
+    if pixel_format == N.PIXELS_F16:
+        return w.view(np.float16).astype(np.int64)
+    return w.view(np.uint16).astype(np.int64)
+
+
+def detect_params(median_filter_size, correlation_matrix, c_std, pixel_format=N.PIXELS_U16):
     K = np.asarray(correlation_matrix)
     if K.ndim != 2 or K.shape[0] != K.shape[1] or K.shape[0] % 2 == 0:
         raise ValueError("correlation_matrix must be square, with an odd number of rows and columns")
@@ -51,6 +81,7 @@ def detect_params(median_filter_size, correlation_matrix, c_std):
     p.median_filter_size = int(median_filter_size)
     p.ksz = int(K.shape[0])
     p.c_std = float(c_std)
+    p.pixel_format = int(pixel_format)
     flat = K.astype(np.int64).ravel()
     for i, v in enumerate(flat):
         p.K[i] = int(v)
@@ -60,12 +91,12 @@ def detect_params(median_filter_size, correlation_matrix, c_std):
 PEAK_RECORD_BYTES = 128 + 200 + 50
 
 
-def split_peak_records(rec):
+def split_peak_records(rec, pixel_format=N.PIXELS_U16):
     """uint8[k, PEAK_RECORD_BYTES] (host) -> (rows FsqRow[k], fit_img float64[k, 5, 5], sub_img int64[k, 5, 5])."""
     rec = np.ascontiguousarray(rec).reshape(-1, PEAK_RECORD_BYTES)
     rows = np.ascontiguousarray(rec[:, :128]).view(N.ROW_DTYPE).reshape(-1)
     fit = np.ascontiguousarray(rec[:, 128:328]).view(np.float64).reshape(-1, 5, 5)
-    sub = np.ascontiguousarray(rec[:, 328:378]).view(np.uint16).reshape(-1, 5, 5).astype(np.int64)
+    sub = pixel_values(np.ascontiguousarray(rec[:, 328:378]).view(np.uint16), pixel_format).reshape(-1, 5, 5)
     return rows, fit, sub
 
 
@@ -136,9 +167,11 @@ class Engine:
         L = N.lib()
         return max(L.fsq_detect_workspace_bytes(n_fields, H, W), L.fsq_consolidate_workspace_bytes(n_fields, H, W))
 
-    def fit(self, d_img, total, mode=N.MODE_REF):
+    def fit(self, d_img, total, mode=N.MODE_REF, pixel_format=N.PIXELS_U16):
         if self.fit_ws is None:
             raise RuntimeError("this Engine was created without a fit workspace (its fits run in a FitQueue)")
+        if pixel_format == N.PIXELS_F16:
+            mode |= N.PIXELS_F16_FLAG
         rc = self.L.fsq_fit_candidates(d_img.data_ptr(), self.n_fields, self.H, self.W, self.cand.data_ptr(), total,
                                        mode, self.rows.data_ptr(), self.fit_ws.data_ptr(), self.fit_ws.numel(),
                                        self._stream())
@@ -156,7 +189,7 @@ class Engine:
         if radius < 2:
             raise ValueError("consolidation_radius must be at least 2")
         total = self.detect(d_img, prm)
-        self.fit(d_img, total, mode)
+        self.fit(d_img, total, mode, prm.pixel_format)
         self.consolidate(r2_threshold, radius, py2_round)
         return total
 
@@ -288,11 +321,11 @@ class FitQueue:
                                            mode, self.stream.cuda_stream), "fsq_fitq_create")
         self.h = h
 
-    def submit(self, d_img, n_fields, H, W, d_cand, n, d_rows):
+    def submit(self, d_img, n_fields, H, W, d_cand, n, d_rows, pixel_format=N.PIXELS_U16):
         """-> ticket, or None when the queue has no room right now (advance and try again)."""
         t = ctypes.c_int(-1)
-        rc = self.L.fsq_fitq_submit(self.h, d_img.data_ptr(), n_fields, H, W, d_cand.data_ptr(), int(n), d_rows.data_ptr(),
-                                    ctypes.byref(t))
+        rc = self.L.fsq_fitq_submit(self.h, d_img.data_ptr(), int(pixel_format), n_fields, H, W, d_cand.data_ptr(), int(n),
+                                    d_rows.data_ptr(), ctypes.byref(t))
         if rc == N.FSQ_EAGAIN:
             return None
         N.check(rc, "fsq_fitq_submit")
@@ -386,10 +419,10 @@ class StreamPipeline:
                         eng = free.pop()
                         total = eng.detect(d_img, prm)          # (synchronises the side stream: the count is needed)
                         totals.append(total)
-                        pending = (j, eng, total, d_img)
+                        pending = (j, eng, total, d_img, prm.pixel_format)
                 if pending is not None and (not inflight or q.alive < self.inject_below):
-                    j, eng, total, d_img = pending
-                    t = q.submit(d_img, eng.n_fields, eng.H, eng.W, eng.cand, total, eng.rows)
+                    j, eng, total, d_img, fmt = pending
+                    t = q.submit(d_img, eng.n_fields, eng.H, eng.W, eng.cand, total, eng.rows, fmt)
                     if t is not None:
                         inflight[t] = pending
                         pending = None
@@ -404,7 +437,7 @@ class StreamPipeline:
                 for t in sorted(inflight, key=lambda k: inflight[k][0]):
                     if not q.take(t, self.side):
                         continue
-                    j, eng, total, d_img = inflight.pop(t)
+                    j, eng, total, d_img, fmt = inflight.pop(t)
                     eng.consolidate(r2_threshold, radius, py2_round)
                     if on_done is not None:
                         on_done(j, eng, total)

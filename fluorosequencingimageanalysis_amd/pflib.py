@@ -31,8 +31,8 @@ PY2_ROUND = True
 
 def _psf_candidates(image, median_filter_size=5, correlation_matrix=default_correlation_matrix, c_std=2, **kwargs):
     """Candidate pixels for PSF fitting, as a list [(h, w), ...] in raster order.  Reference pflib.py:217-258."""
-    prm = _engine.detect_params(median_filter_size, correlation_matrix, c_std)      # ValueError as pflib.py:236-239
-    img = _engine.as_u16_fields(image)
+    img, fmt = _engine.as_pixel_fields(image)
+    prm = _engine.detect_params(median_filter_size, correlation_matrix, c_std, fmt)  # ValueError as pflib.py:236-239
     if img.ndim != 2:
         raise ValueError("image must be two-dimensional")
     H, W = img.shape
@@ -91,11 +91,11 @@ def _records_to_dicts(rows, fit, sub, offs, failed=()):
     return out
 
 
-def _engine_dicts(eng, d_img):
+def _engine_dicts(eng, d_img, pixel_format=N.PIXELS_U16):
     """Consolidated results of an Engine pass -> list of per-field dicts (AssertionError instances for failed fields)."""
     rec, offs = eng.peak_records(d_img)
     nkeep = eng.nkeep.cpu().numpy()
-    rows, fit, sub = _engine.split_peak_records(rec.cpu().numpy())
+    rows, fit, sub = _engine.split_peak_records(rec.cpu().numpy(), pixel_format)
     failed = set(int(f) for f in np.nonzero(nkeep[:eng.n_fields] < 0)[0])
     return _records_to_dicts(rows, fit, sub, offs.cpu().numpy(), failed)
 
@@ -118,8 +118,8 @@ def find_peptides_batch(images, median_filter_size=5, correlation_matrix=default
         raise NotImplementedError("fit_type='monte_carlo' draws from an unseeded RNG in the reference "
                                   "(pflib.py:117-177) and is not reproduced")
     # (candidate_pixels: "Not yet implemented" in the reference, pflib.py:374 - accepted and ignored there and here)
-    prm = _engine.detect_params(median_filter_size, correlation_matrix, c_std)
-    imgs = _engine.as_u16_fields(images)
+    imgs, fmt = _engine.as_pixel_fields(images)            # integer dtypes, or float16 (fp16 pixel loads)
+    prm = _engine.detect_params(median_filter_size, correlation_matrix, c_std, fmt)
     if imgs.ndim != 3:
         raise ValueError("images must have shape (n, H, W)")
     n, H, W = imgs.shape
@@ -130,7 +130,7 @@ def find_peptides_batch(images, median_filter_size=5, correlation_matrix=default
         eng = engine or _engine.Engine(n, H, W)
         d_img = _engine.to_device_u16(imgs)
         eng.run(d_img, prm, r_2_threshold, consolidation_radius, N.MODE_REF, PY2_ROUND)
-        out = _engine_dicts(eng, d_img)
+        out = _engine_dicts(eng, d_img, fmt)
     else:
         n_chunks = -(-n // per)
         per = -(-n // n_chunks)
@@ -148,7 +148,7 @@ def find_peptides_batch(images, median_filter_size=5, correlation_matrix=default
                 yield bufs[c], prm
 
         def on_done(c, eng, total):
-            out[c * per:(c + 1) * per] = _engine_dicts(eng, bufs.pop(c))
+            out[c * per:(c + 1) * per] = _engine_dicts(eng, bufs.pop(c), fmt)
 
         try:
             pipe.run(jobs(), on_done, r_2_threshold, consolidation_radius, PY2_ROUND)

@@ -35,6 +35,7 @@ extern "C" {
 
 #define FSQ_MODE_REF      0 /* reference-faithful fp64 LM (qrsolv/diag(R) aliasing of mpfit.py:1915) */
 #define FSQ_MODE_TEXTBOOK 1 /* same solver with MINPACK's diagonal restore */
+#define FSQ_PIXELS_F16_FLAG 0x1000 /* OR into mode (fsq_fit_candidates): d_img holds FSQ_PIXELS_F16 pixels */
 #define FSQ_ENGINE_LANE 0x100 /* OR into mode: persistent kernel, one GPU lane per fit (A/B timing only) */
 #define FSQ_ENGINE_QUAD 0x200 /* OR into mode: persistent kernel, a quad of lanes per fit (A/B timing only) */
 
@@ -48,11 +49,24 @@ typedef struct FsqRow {
     int32_t key_h, key_w;                           /* dict key after consolidation (rounded centre) */
 } FsqRow;
 
+/*
+ * Pixel storage formats of the image arguments.  The reference works on `image.astype(np.int64)` whatever dtype it is
+ * handed (pflib.py:241, 443); the GPU path keeps images in HBM as 16-bit words:
+ *   FSQ_PIXELS_U16  unsigned 16-bit integers (TIRF camera frames)
+ *   FSQ_PIXELS_F16  IEEE binary16 holding the (pre-scaled, BASELINE.json configs[4]) intensities; a pixel's integer value
+ *                   is the half truncated toward zero, exactly what astype(int64) gives for a float16 image
+ *                   (negative / NaN -> 0, +inf -> 65535).  Same bytes per pixel, same fp64 solver behind the load.
+ */
+#define FSQ_PIXELS_U16 0
+#define FSQ_PIXELS_F16 1
+
 typedef struct FsqDetectParams {
     int32_t median_filter_size;                     /* pflib default 5 */
     int32_t ksz;                                    /* correlation_matrix side, odd */
     double c_std;                                   /* pflib default 2 */
     int64_t K[81];                                  /* correlation_matrix, row-major, ksz <= 9 */
+    int32_t pixel_format;                           /* FSQ_PIXELS_U16 / FSQ_PIXELS_F16 of d_img */
+    int32_t reserved;
 } FsqDetectParams;
 
 const char* fsq_version(void);
@@ -64,7 +78,7 @@ int64_t fsq_detect_workspace_bytes(int n_fields, int H, int W);
 
 /*
  * Candidate detection for a batch of fields (raster order inside each field, fields in order).
- *   d_img     uint16[n_fields][H][W]
+ *   d_img     uint16[n_fields][H][W] (or binary16, prm->pixel_format)
  *   d_cand    int32[cap][3]  (field, h, w)            out
  *   d_counts  int32[n_fields + 1]                      out: per-field candidate counts, [n_fields] = total
  *             (total = -1: the response image of some field sums to >= 2^53, where numpy.mean of the reference
@@ -121,8 +135,8 @@ int fsq_fitq_create(FsqFitQueue** q, void* d_workspace, int64_t workspace_bytes,
 /* Add a batch (same arguments as fsq_fit_candidates; d_img / d_cand / d_rows must stay valid until the batch has been
  * taken).  Work enqueued on the queue's stream so far must not still be writing d_cand (order it with an event or
  * synchronise).  *ticket names the batch.  FSQ_EAGAIN: no free slots / tickets now. */
-int fsq_fitq_submit(FsqFitQueue* q, const uint16_t* d_img, int n_fields, int H, int W, const int32_t* d_cand, int64_t n,
-                    FsqRow* d_rows, int* ticket);
+int fsq_fitq_submit(FsqFitQueue* q, const void* d_img, int pixel_format, int n_fields, int H, int W, const int32_t* d_cand,
+                    int64_t n, FsqRow* d_rows, int* ticket);
 /* Run rounds until at least one batch has finished, or nothing is alive, or fewer than alive_below fits are alive, or
  * max_rounds (> 0) rounds have run.  *alive = fits still alive, *finished = batches that finished during the call. */
 int fsq_fitq_advance(FsqFitQueue* q, int64_t max_rounds, int64_t alive_below, int64_t* alive, int* finished);

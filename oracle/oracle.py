@@ -152,3 +152,43 @@ def gaussian_volume(fit7, scaling=10 ** 6):
     """Spot.gaussian_volume_photometry_metric (flexlibrary.py:212-230): float(scaling) * A * sigma_h * sigma_w."""
     f = np.asarray(fit7, dtype=np.float64)
     return (float(scaling) * f[:, 3]) * f[:, 4] * f[:, 5]
+
+
+def euclid2(dh, dw):
+    """scipy.spatial.distance.euclidean of a 2-vector of differences as OpenBLAS dnrm2 evaluates it (x87 extended)."""
+    L = lib()
+    L.fsq_o_euclid2.restype = ctypes.c_double
+    L.fsq_o_euclid2.argtypes = [ctypes.c_double, ctypes.c_double]
+    return L.fsq_o_euclid2(float(dh), float(dw))
+
+
+def greedy_tracking(frame_hw, offsets, shape, candidate_radius=2, spot_radius=0.0):
+    """Experiment.greedy_particle_tracking (flexlibrary.py:680-1027) for one field.
+    frame_hw: list (per frame) of int arrays [n_f, 2] (Spot.h, Spot.w); offsets: [(d_h, d_w)] relative to the previous
+    frame.  Returns (traces int32[n_traces, n_frames] of global spot numbers / -1, n_discarded, link_prev, link_next, kept)."""
+    counts = np.array([len(x) for x in frame_hw], dtype=np.int32)
+    hw = (np.concatenate([np.asarray(x, dtype=np.int32).reshape(-1, 2) for x in frame_hw])
+          if counts.sum() else np.zeros((0, 2), np.int32))
+    hw = np.ascontiguousarray(hw, dtype=np.int32)
+    off = np.ascontiguousarray(np.asarray(offsets, dtype=np.float64).reshape(-1, 2))
+    n = int(counts.sum())
+    F = len(counts)
+    prev = np.full(n + 1, -1, np.int32)
+    nxt = np.full(n + 1, -1, np.int32)
+    kept = np.zeros(n + 1, np.uint8)
+    traces = np.full((n + 1, F), -1, np.int32)
+    nt, nd = ctypes.c_int32(), ctypes.c_int32()
+    L = lib()
+    L.fsq_o_greedy_tracking.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    rc = L.fsq_o_greedy_tracking(F, _p(counts), _p(hw), _p(off), int(shape[0]), int(shape[1]), int(candidate_radius),
+                                 float(spot_radius), _p(prev), _p(nxt), _p(kept), _p(traces), n + 1,
+                                 ctypes.byref(nt), ctypes.byref(nd))
+    if rc == -1:
+        raise ValueError("The first image's offset must be (0, 0) by definiton.")
+    if rc == -2:
+        raise AssertionError("bin already filled in frame_bins (flexlibrary.py:851)")
+    if rc < 0:
+        raise RuntimeError("oracle greedy_tracking error %d" % rc)
+    return traces[:nt.value].copy(), nd.value, prev[:n].copy(), nxt[:n].copy(), kept[:n].astype(bool)

@@ -103,5 +103,9 @@ def load_flexlibrary(ref=None):
         meas = types.ModuleType("scipy.ndimage.measurements")
         meas.center_of_mass = scipy.ndimage.center_of_mass
         sys.modules["scipy.ndimage.measurements"] = meas
-    ref.fl = load("flexlibrary", "flexlibrary.py")
+    libm = ctypes.CDLL("libm.so.6")
+    libm.round.restype = ctypes.c_double
+    libm.round.argtypes = [ctypes.c_double]
+    # Python-2 round() (half away from zero) for the bin coordinates of the tracking code (flexlibrary.py:850, 880)
+    ref.fl = load("flexlibrary", "flexlibrary.py", inject={"round": lambda x: libm.round(float(x))})
     return ref

@@ -97,6 +97,73 @@ def test_config2_full_size_replicated_golden(env):
     assert (keep - (np.arange(n) * ncand)[:, None] == keep[0][None]).all()  # same kept candidates in the same order
 
 
+def test_config4_per_rank_share_2048_fields(env):
+    """configs[3] (16 384 fields over 8 GPUs) gives every rank 2 048 fields of 512x512: that share in ONE engine pass
+    (8.7 M LM solves), every field a copy of golden field f1, so every field must reproduce the reference's table."""
+    torch, N, E, pflib, pc, synth, O = env
+    g, img = load_field("f1_cfg2_512_500")
+    n = 2048
+    d_img = E.to_device_u16(img[None]).expand(n, -1, -1).contiguous()
+    eng = E.Engine(n, 512, 512)
+    total = eng.run(d_img, E.detect_params(5, pflib.default_correlation_matrix, 2))
+    ncand = len(g["candidates"])
+    assert total == n * ncand and N.lib().fsq_fit_last_slow_count() == 0
+    rows = eng.rows[:total].cpu().numpy().view(N.ROW_DTYPE).reshape(n, ncand)
+    p = np.stack([rows[k] for k in ("H", "A", "p2", "p3", "sigma_h", "sigma_w", "theta")], axis=-1)
+    assert bits_equal(p[0], g["params"]).all() and (p.view(np.uint64) == p[0].view(np.uint64)[None]).all()
+    assert (rows["status"] == g["status"][None]).all() and (rows["nfev"] == g["nfev"][None]).all()
+    table, offs = eng.kept_table()
+    offs = offs.cpu().numpy()
+    nk = len(g["table_keys"])
+    assert (np.diff(offs) == nk).all()
+    t = table.cpu().numpy().view(N.ROW_DTYPE).reshape(n, nk)
+    assert (t["key_h"] == g["table_keys"][None, :, 0]).all() and (t["key_w"] == g["table_keys"][None, :, 1]).all()
+    assert bits_equal(np.stack([t[0][k] for k in ("h0", "w0", "H", "A", "sigma_h", "sigma_w", "theta")], axis=1), g["table7"]).all()
+
+
+def test_config5_fp16_pixel_loads(env):
+    """configs[4]: 2 048x2 048 high-density field stored as binary16 (pre-scaled to fit its range), loaded as fp16 by the
+    detection and fit kernels and fed to the same fp64 solver - equal, bit for bit, to the oracle run on the
+    fp16-quantised pixels.  One frame at camera brightness (exact below 2 048 counts, even values
+    above) and one brightened x25 so that the pre-scaling is not the identity."""
+    torch, N, E, pflib, pc, synth, O = env
+    base = synth.make_field(78, (2048, 2048), 5000)
+    for gain in (1, 25):
+        img = np.minimum(base.astype(np.int64) * gain, 65535).astype(np.uint16)
+        f16, scale = E.quantise_f16(img)
+        assert f16.dtype == np.float16 and (scale < 1.0) == (gain == 25)
+        q = f16.astype(np.int64)                                     # what image.astype(np.int64) gives the reference
+        assert (q != img).any() and q.max() <= 65504
+        cand = pflib._psf_candidates(f16)
+        exp = O.candidates(q.astype(np.uint16))
+        assert len(cand) == len(exp) and np.array_equal(np.array(cand), exp)
+        got = pflib.find_peptides(f16)
+        rows, fits, keep, key = O.find_peptides(q.astype(np.uint16), n_threads=16)
+        _same_table(got, rows, fits, keep, key)
+        v = next(iter(got.values()))
+        h, w = int(rows[keep][0]["h"]), int(rows[keep][0]["w"])
+        assert v[7].dtype == np.int64 and np.array_equal(v[7], q[h - 2:h + 3, w - 2:w + 3])
+    # the same through the stream pipeline (fit queue) on a small fp16 batch
+    small = np.stack([synth.make_field(90 + i, (128, 128), 25) for i in range(4)])
+    f16, _ = E.quantise_f16(small * 30)
+    one = pflib.find_peptides_batch(f16)
+    for i in range(4):
+        rows, fits, keep, key = O.find_peptides(f16[i].astype(np.int64).astype(np.uint16), n_threads=8)
+        _same_table(one[i], rows, fits, keep, key)
+    words, fmt = E.as_pixel_fields(f16)
+    assert fmt == N.PIXELS_F16
+    pipe = E.StreamPipeline(4, 128, 128, depth=3, inject_below=1 << 40)
+    prm = E.detect_params(5, pflib.default_correlation_matrix, 2, fmt)
+    d = E.to_device_u16(words)
+    out = {}
+    pipe.run([(d, prm)] * 3, lambda j, eng, total: out.__setitem__(j, pflib._engine_dicts(eng, d, fmt)))
+    pipe.close()
+    for j in range(3):
+        for a, b in zip(out[j], one):
+            assert list(a.keys()) == list(b.keys())
+            assert all(bits_equal(np.array([float(x) for x in a[k][:7]]), np.array([float(x) for x in b[k][:7]])).all() for k in a)
+
+
 def test_lane_pipeline_equals_single_engine(env):
     """engine.LanePipeline (two shares on their own streams / host threads, second one staggered) returns exactly what
     one engine returns for the same fields."""

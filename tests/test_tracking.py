@@ -1,0 +1,65 @@
+"""CPU tests (-m "not gpu") of the tracking oracle (oracle/fsq_track_oracle.c) against outputs of the
+reference's own Experiment.greedy_particle_tracking (flexlibrary.py:680-1027), recorded by
+oracle/gen_golden.py --only track into tests/golden/tracking.npz."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from _util import GOLD
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build():
+    O.build()
+
+
+def load_cases():
+    g = np.load(os.path.join(GOLD, "tracking.npz"))
+    for name in g["names"]:
+        name = str(name)
+        counts = g[name + "_counts"]
+        hw = g[name + "_hw"]
+        cuts = np.concatenate([[0], np.cumsum(counts)])
+        frame_hw = [hw[cuts[f]:cuts[f + 1]] for f in range(len(counts))]
+        yield (name, frame_hw, [tuple(o) for o in g[name + "_offsets"]], tuple(int(x) for x in g[name + "_shape"]),
+               int(g[name + "_radius"][0]), float(g[name + "_radius"][1]), g[name + "_traces"], int(g[name + "_discarded"]))
+
+
+def test_tracking_goldens_cover_the_cases():
+    names = [c[0] for c in load_cases()]
+    assert {"stack256", "stack512", "ties_int", "drift_dropout", "drift_radius3_edge2", "compete", "empty_frames"} <= set(names)
+
+
+@pytest.mark.parametrize("case", list(load_cases()), ids=lambda c: c[0])
+def test_oracle_tracking_equals_reference(case):
+    """Trace membership and order, and the number of spots discarded for drifting out of the field, exactly."""
+    name, frame_hw, offsets, shape, radius, spot_radius, traces, discarded = case
+    got, nd, prev, nxt, kept = O.greedy_tracking(frame_hw, offsets, shape, radius, spot_radius)
+    assert nd == discarded
+    assert got.shape == traces.shape and np.array_equal(got, traces)
+    assert int((~kept).sum()) == discarded
+
+
+def test_euclid_is_dnrm2_of_this_scipy():
+    """The pair distance: scipy.spatial.distance.euclidean (flexlibrary.py:927) = OpenBLAS dnrm2, x87 extended precision -
+    the oracle's restatement equals it on every one of 50 000 displacement vectors (plain double arithmetic does not)."""
+    from scipy.spatial.distance import euclidean
+    rng = np.random.default_rng(1)
+    a = np.round(rng.uniform(-3, 3, (50000, 2)) * 20) / 20 + rng.integers(0, 500, (50000, 2))
+    b = a + np.round(rng.uniform(-2.5, 2.5, (50000, 2)) * 20) / 20
+    b[:1000] = a[:1000] + rng.uniform(-3, 3, (1000, 2))
+    plain = 0
+    for u, v in zip(a, b):
+        d = u - v
+        assert euclidean(u, v) == O.euclid2(d[0], d[1])
+        plain += euclidean(u, v) != np.sqrt(d[0] * d[0] + d[1] * d[1])
+    assert plain > 1000
+
+
+def test_tracking_errors():
+    with pytest.raises(ValueError):                     # flexlibrary.py:581-583
+        O.greedy_tracking([np.array([[5, 5]])], [(1, 0)], (12, 12))
+    with pytest.raises(AssertionError):                 # two spots of one frame in one bin, flexlibrary.py:851-856
+        O.greedy_tracking([np.array([[5, 5], [5, 5]])], [(0, 0)], (12, 12))
