@@ -1,0 +1,155 @@
+"""Drop-in for the tracking entry points of the reference's `flexlibrary.Experiment`, computed on
+the GPU from the peak tables:
+
+    Experiment.accumulate_offsets        flexlibrary.py:567-593
+    Experiment.discard_dropouts          flexlibrary.py:626-678
+    Experiment.greedy_particle_tracking  flexlibrary.py:680-1027
+
+Same names, arguments, return shapes and exceptions; `track_fields` is the batch form (many fields per launch) that
+works directly on `(h, w)` tables such as the dict keys pflib.find_peptides returns.  The arithmetic is in
+csrc/fsq_track.hip (fsq_greedy_tracking of include/fsq.h); there is no CPU fallback."""
+import ctypes
+
+import numpy as np
+
+from . import _native as N
+from . import engine as _engine
+from .pflib import _py2_round
+
+
+def track_fields(fields, offsets, frame_shape, candidate_radius=2, spot_radius=0, device=None):
+    """Track the spots of many independent fields in one launch.
+
+    fields:  list (per field) of lists (per frame) of integer arrays [n, 2] = (Spot.h, Spot.w); every field has the same
+             number of frames.
+    offsets: list (per field) of lists (per frame) of (d_h, d_w) relative to the previous frame, offsets[k][0] == (0, 0).
+    Returns a list (per field) of (traces int32[n_traces, n_frames], n_discarded, prev int32[n], next int32[n],
+    kept bool[n]): spot numbers count through the field's frames in order, -1 = no spot.  Raises ValueError /
+    AssertionError where the reference does (first offset not (0, 0); two spots of one frame in one bin)."""
+    torch = _engine._torch()
+    dev = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
+    if int(candidate_radius) != candidate_radius:
+        raise TypeError("slice indices must be integers")          # the reference slices with candidate_radius (:905)
+    n_fields = len(fields)
+    if n_fields == 0:
+        return []
+    F = len(fields[0])
+    H, W = int(frame_shape[0]), int(frame_shape[1])
+    counts = np.zeros((n_fields, F), np.int32)
+    parts = []
+    for k, frames in enumerate(fields):
+        if len(frames) != F or len(offsets[k]) != F:
+            raise ValueError("every field needs the same number of frames and one offset per frame")
+        for f, hw in enumerate(frames):
+            a = np.asarray(hw)
+            if a.size and not np.array_equal(a, np.rint(a)):
+                raise NotImplementedError("Spot.h / Spot.w must be whole numbers (flexlibrary.py:449 makes them so)")
+            a = a.astype(np.int32).reshape(-1, 2)
+            counts[k, f] = len(a)
+            parts.append(a)
+    hw = np.ascontiguousarray(np.concatenate(parts) if parts else np.zeros((0, 2), np.int32))
+    start = np.concatenate([[0], np.cumsum(counts.sum(axis=1))]).astype(np.int32)
+    total = int(start[-1])
+    off = np.ascontiguousarray(np.array([[(float(o[0]), float(o[1])) for o in offs] for offs in offsets], dtype=np.float64))
+    pair_cap = max(4096, 8 * int(counts.max()) if counts.size else 4096)
+    L = N.lib()
+    ws_bytes = L.fsq_track_workspace_bytes(n_fields, H, W, pair_cap)
+    if ws_bytes < 0:
+        raise ValueError("invalid tracking shape")
+    t = lambda a: torch.from_numpy(a).to(dev)          # noqa: E731
+    d_hw, d_start, d_counts, d_off = t(hw.reshape(-1)), t(start), t(counts.reshape(-1)), t(off.reshape(-1))
+    d_prev = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+    d_next = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+    d_kept = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
+    d_traces = torch.empty(max(total, 1) * F, dtype=torch.int32, device=dev)
+    d_nt = torch.empty(n_fields, dtype=torch.int32, device=dev)
+    d_nd = torch.empty(n_fields, dtype=torch.int32, device=dev)
+    d_st = torch.empty(n_fields, dtype=torch.int32, device=dev)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    rc = L.fsq_greedy_tracking(d_hw.data_ptr(), d_start.data_ptr(), d_counts.data_ptr(), d_off.data_ptr(), n_fields, F, H, W,
+                               int(candidate_radius), float(spot_radius), d_prev.data_ptr(), d_next.data_ptr(),
+                               d_kept.data_ptr(), d_traces.data_ptr(), d_nt.data_ptr(), d_nd.data_ptr(), d_st.data_ptr(),
+                               pair_cap, ws.data_ptr(), ws_bytes, torch.cuda.current_stream(dev).cuda_stream)
+    N.check(rc, "fsq_greedy_tracking")
+    st, nt, nd = d_st.cpu().numpy(), d_nt.cpu().numpy(), d_nd.cpu().numpy()
+    prev, nxt, kept = d_prev.cpu().numpy(), d_next.cpu().numpy(), d_kept.cpu().numpy().astype(bool)
+    traces = d_traces.cpu().numpy().reshape(-1, F)
+    out = []
+    for k in range(n_fields):
+        if st[k] == N.FSQ_EINVAL:
+            raise ValueError("The first image's offset must be (0, 0) by definiton.")           # flexlibrary.py:581-583
+        if st[k] == N.FSQ_EASSERT:
+            raise AssertionError("field %d: two spots of one frame round to the same bin of frame_bins "
+                                 "(flexlibrary.py:851)" % k)
+        N.check(int(st[k]), "fsq_greedy_tracking (field %d)" % k)
+        a, b = int(start[k]), int(start[k + 1])
+        out.append((traces[a:a + int(nt[k])].copy(), int(nd[k]), prev[a:b].copy(), nxt[a:b].copy(), kept[a:b].copy()))
+    return out
+
+
+class Experiment(object):
+    """The static tracking helpers of the reference's Experiment class."""
+
+    @staticmethod
+    def accumulate_offsets(offsets):
+        """Offsets relative to the preceding image -> offsets relative to the first.  flexlibrary.py:567-593."""
+        if offsets[0] != (0, 0):
+            raise ValueError("The first image's offset must be (0, 0) by definiton.")
+        return [(sum([o[0] for o in offsets[:f + 1]]), sum([o[1] for o in offsets[:f + 1]])) for f in range(len(offsets))]
+
+    @staticmethod
+    def get_cumulative_offset(offsets, f, g=0):
+        """Cumulative offset of frame f with respect to frame g.  flexlibrary.py:595-601."""
+        cf = Experiment.accumulate_offsets(offsets)[f]
+        cg = Experiment.accumulate_offsets(offsets)[g]
+        return (cf[0] - cg[0], cf[1] - cg[1])
+
+    @staticmethod
+    def round_coordinates(h, w):
+        return int(_py2_round(h)), int(_py2_round(w))             # flexlibrary.py:603-605 (Python 2 round)
+
+    @staticmethod
+    def apply_offset(coordinates, offset):
+        return coordinates[0] + offset[0], coordinates[1] + offset[1]
+
+    @staticmethod
+    def unapply_offset(offset_coordinates, offset):
+        return offset_coordinates[0] - offset[0], offset_coordinates[1] - offset[1]
+
+    @staticmethod
+    def offset_frame_coordinates(offsets, coordinate, f, g):
+        """Given a coordinate in frame g, its coordinate in frame f.  flexlibrary.py:619-624."""
+        return Experiment.apply_offset(coordinate, Experiment.get_cumulative_offset(offsets=offsets, f=f, g=g))
+
+    @staticmethod
+    def discard_dropouts(spots, spot_cumulative_offsets, frame_cumulative_offsets, image_shape, spot_radius=0):
+        """Drop the Spots whose position falls outside some frame of the sequence.  flexlibrary.py:626-678.
+        (Host arithmetic: a handful of comparisons per spot; the tracking kernel applies the same rule itself.)"""
+        filtered, discarded = [], 0
+        for i, spot in enumerate(spots):
+            oh, ow = Experiment.apply_offset((spot.h, spot.w), spot_cumulative_offsets[i])
+            for offset in frame_cumulative_offsets:
+                gh, gw = Experiment.unapply_offset((oh, ow), offset)
+                if not (spot_radius <= gh < image_shape[0] - 0.5 - spot_radius and
+                        spot_radius <= gw < image_shape[1] - 0.5 - spot_radius):
+                    discarded += 1
+                    break
+            else:
+                filtered.append(spot)
+        return filtered, discarded
+
+    @staticmethod
+    def greedy_particle_tracking(frame_spots, frame_shape, candidate_radius=2, offsets=None, spot_radius=0):
+        """Track Spots across frames.  flexlibrary.py:680-1027.
+
+        frame_spots: iterable (frames) of iterables of objects with integer `.h` / `.w`; offsets: (delta_h, delta_w) of
+        every frame relative to the one before.  Returns (traces, number of discarded spots): one list per tracked spot
+        holding its Spot object (or None) for every frame, in the reference's order."""
+        frame_spots = [list(fr) for fr in frame_spots]
+        if offsets is None:
+            raise TypeError("'int' object is not iterable")       # the reference's default branch fails the same way (:787)
+        res = track_fields([[np.array([(s.h, s.w) for s in fr]).reshape(-1, 2) for fr in frame_spots]],
+                           [list(offsets)], frame_shape, candidate_radius, spot_radius)[0]
+        flat = [s for fr in frame_spots for s in fr]
+        traces = [[(flat[i] if i >= 0 else None) for i in row] for row in res[0]]
+        return traces, res[1]

@@ -202,6 +202,38 @@ int fsq_mexican_hat(const uint16_t* d_img, int n_fields, int H, int W, const int
                     int brim_size, int radius, double* d_out, void* stream);
 
 /*
+ * Greedy particle tracking of the peak tables across the frames of a field:
+ * Experiment.greedy_particle_tracking with accumulate_offsets and discard_dropouts, flexlibrary.py:567-1027.
+ * One call tracks n_fields independent fields of n_frames frames each.
+ *   d_hw           int32[total][2]   Spot.h, Spot.w (the dict keys pflib.find_peptides returns = FsqRow.key_h / key_w),
+ *                                    field after field, frame after frame inside a field
+ *   d_field_start  int32[n_fields+1] first spot of every field in d_hw ([n_fields] = total)
+ *   d_counts       int32[n_fields][n_frames]  spots per frame
+ *   d_offsets      double[n_fields][n_frames][2]  (d_h, d_w) of every frame relative to the frame before it
+ *                                    (SequenceExperiment.offsets_from_frames, flexlibrary.py:1717-1741); [0] must be (0, 0)
+ *   candidate_radius, spot_radius    as the reference's arguments (defaults 2 and 0)
+ * Outputs, spot numbers counted from the field's first spot, -1 = none:
+ *   d_prev, d_next int32[total]      ancestor / descendant link of every spot
+ *   d_kept         uint8[total]      0 = discarded because it drifts out of some frame (discard_dropouts)
+ *   d_traces       int32[total][n_frames]  field f's traces are rows field_start[f] .. +n_traces[f], in the reference's
+ *                                    order (heads by frame, then by bin in raster order); one spot number or -1 per frame
+ *   d_n_traces, d_n_discarded, d_status  int32[n_fields]; status: 0, FSQ_EINVAL (offsets[0] != (0,0): the reference's
+ *                                    ValueError), FSQ_EASSERT (two spots of a frame in one bin: its AssertionError,
+ *                                    flexlibrary.py:851), FSQ_ERANGE (more than pair_cap candidate pairs in one frame)
+ *   pair_cap       capacity of the per-frame candidate-pair list (a few times the spots per frame)
+ * At most 64 frames and 32 768 spots per field.  Enqueue only.
+ */
+int64_t fsq_track_workspace_bytes(int n_fields, int H, int W, int64_t pair_cap);
+int fsq_greedy_tracking(const int32_t* d_hw, const int32_t* d_field_start, const int32_t* d_counts, const double* d_offsets,
+                        int n_fields, int n_frames, int H, int W, int candidate_radius, double spot_radius,
+                        int32_t* d_prev, int32_t* d_next, uint8_t* d_kept, int32_t* d_traces, int32_t* d_n_traces,
+                        int32_t* d_n_discarded, int32_t* d_status, int64_t pair_cap, void* d_workspace,
+                        int64_t workspace_bytes, void* stream);
+/* fsq_selftest_dnrm2: the tracking kernel's pair distance (OpenBLAS dnrm2 in x87 extended precision, restated in
+ * integer arithmetic, csrc/fsq_x87.h) for caller-supplied displacement vectors; d_out[i] = dnrm2((d_dh[i], d_dw[i])). */
+int fsq_selftest_dnrm2(const double* d_dh, const double* d_dw, int64_t n, double* d_out, void* stream);
+
+/*
  * Self-test hooks of the LM fit (no reference counterpart).
  * fsq_selftest_division: the fit kernel divides by shared divisors through a hoisted reciprocal that is
  *   bit-identical to the compiler's fp64 division inside a guarded operand range (fsq_devmath.h); this counts

@@ -1,0 +1,113 @@
+"""GPU tests (-m gpu) of the tracking kernel (csrc/fsq_track.hip): trace membership and order equal to
+the reference's Experiment.greedy_particle_tracking as recorded in tests/golden/tracking.npz, and to the oracle on
+random layouts; the integer restatement of the x87 dnrm2 distance against the oracle's long-double form."""
+import numpy as np
+import pytest
+
+from test_tracking import load_cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from fluorosequencingimageanalysis_amd import _native, flexlibrary
+    import oracle as O
+    O.build()
+    return torch, _native, flexlibrary, O
+
+
+@pytest.mark.parametrize("case", list(load_cases()), ids=lambda c: c[0])
+def test_tracking_equals_reference(env, case):
+    torch, N, fl, O = env
+    name, frame_hw, offsets, shape, radius, spot_radius, traces, discarded = case
+    got, nd, prev, nxt, kept = fl.track_fields([frame_hw], [offsets], shape, radius, spot_radius)[0]
+    assert nd == discarded and got.shape == traces.shape and np.array_equal(got, traces)
+    o_tr, o_nd, o_prev, o_next, o_kept = O.greedy_tracking(frame_hw, offsets, shape, radius, spot_radius)
+    assert np.array_equal(prev, o_prev) and np.array_equal(nxt, o_next) and np.array_equal(kept, o_kept)
+
+
+def test_tracking_batch_and_object_surface(env):
+    """Many fields per launch (random layouts vs the oracle), and the Experiment.greedy_particle_tracking surface on
+    Spot-like objects."""
+    torch, N, fl, O = env
+    rng = np.random.default_rng(5)
+    fields, offs = [], []
+    F, shape = 6, (96, 128)
+    for k in range(40):
+        base = rng.integers(4, 90, (60, 2)).astype(np.int64)
+        base[:, 1] = rng.integers(4, 122, 60)
+        base = base[np.unique(base[:, 0] * 1000 + base[:, 1], return_index=True)[1]]
+        frames, o, cum = [], [(0, 0)], np.zeros(2)
+        for f in range(F):
+            if f:
+                step = np.round(rng.uniform(-2, 2, 2) * 20) / 20
+                o.append((float(step[0]), float(step[1])))
+                cum = cum + step
+            pts = np.rint(base - cum).astype(np.int64) + rng.integers(-1, 2, base.shape)
+            pts = pts[rng.uniform(size=len(pts)) > 0.2]
+            pts = pts[np.unique(pts[:, 0] * 1000 + pts[:, 1], return_index=True)[1]]
+            frames.append(pts)
+        fields.append(frames)
+        offs.append(o)
+    res = fl.track_fields(fields, offs, shape)
+    n_checked = 0
+    for frames, o, r in zip(fields, offs, res):
+        try:
+            exp = O.greedy_tracking(frames, o, shape)
+        except AssertionError:
+            continue
+        assert np.array_equal(r[0], exp[0]) and r[1] == exp[1]
+        assert np.array_equal(r[2], exp[2]) and np.array_equal(r[3], exp[3]) and np.array_equal(r[4], exp[4])
+        n_checked += 1
+    assert n_checked >= 30
+
+    class Spot(object):
+        def __init__(self, h, w):
+            self.h, self.w = int(h), int(w)
+    name, frame_hw, offsets, shape, radius, spot_radius, traces, discarded = next(c for c in load_cases() if c[0] == "stack256")
+    frame_spots = [[Spot(h, w) for h, w in hw] for hw in frame_hw]
+    tr, nd = fl.Experiment.greedy_particle_tracking(frame_spots, shape, offsets=offsets)
+    flat = [s for fr in frame_spots for s in fr]
+    assert nd == discarded and len(tr) == len(traces)
+    for row, exp in zip(tr, traces):
+        assert [(-1 if s is None else flat.index(s)) for s in row] == list(exp)
+    assert fl.Experiment.accumulate_offsets(offsets)[3] == (sum(o[0] for o in offsets[:4]), sum(o[1] for o in offsets[:4]))
+
+
+def test_tracking_errors(env):
+    torch, N, fl, O = env
+    with pytest.raises(ValueError):                     # flexlibrary.py:581-583
+        fl.track_fields([[np.array([[5, 5]])]], [[(1, 0)]], (12, 12))
+    with pytest.raises(AssertionError):                 # flexlibrary.py:851-856
+        fl.track_fields([[np.array([[5, 5], [5, 5]])]], [[(0, 0)]], (12, 12))
+    with pytest.raises(ValueError):
+        fl.Experiment.accumulate_offsets([(0, 1), (0, 0)])
+    with pytest.raises(TypeError):
+        fl.Experiment.greedy_particle_tracking([[]], (8, 8))
+
+
+def test_x87_dnrm2_restatement(env):
+    """fsq_dnrm2_2 (integer arithmetic on 64-bit significands) == the oracle's long-double chain on 2 M vectors:
+    the 1/20-pixel grid of registration offsets, arbitrary doubles, wide exponent ranges, zeros."""
+    torch, N, fl, O = env
+    rng = np.random.default_rng(11)
+    n = 500000
+    dh = np.concatenate([rng.integers(-60, 61, n) / 20.0, rng.uniform(-3, 3, n), rng.uniform(-1000, 1000, n),
+                         np.ldexp(rng.uniform(-2, 2, n), rng.integers(-200, 200, n)), [0.0, 0.0, 3.0, -0.0]])
+    dw = np.concatenate([rng.integers(-60, 61, n) / 20.0, rng.uniform(-3, 3, n), rng.uniform(-3, 3, n) * 1e-3,
+                         np.ldexp(rng.uniform(-2, 2, n), rng.integers(-200, 200, n)), [0.0, 1.5, 4.0, 2.0]])
+    d_h, d_w = torch.from_numpy(dh).cuda(), torch.from_numpy(dw).cuda()
+    out = torch.empty_like(d_h)
+    N.check(N.lib().fsq_selftest_dnrm2(d_h.data_ptr(), d_w.data_ptr(), len(dh), out.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream), "fsq_selftest_dnrm2")
+    got = out.cpu().numpy()
+    import ctypes
+    L = O.lib()
+    L.fsq_o_euclid2.restype = ctypes.c_double
+    L.fsq_o_euclid2.argtypes = [ctypes.c_double, ctypes.c_double]
+    exp = np.array([L.fsq_o_euclid2(a, b) for a, b in zip(dh, dw)])
+    assert np.array_equal(got.view(np.uint64), exp.view(np.uint64))
+    assert (exp != np.sqrt(dh * dh + dw * dw)).mean() > 0.05           # ...and plain double arithmetic is not the same

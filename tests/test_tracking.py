@@ -63,3 +63,14 @@ def test_tracking_errors():
         O.greedy_tracking([np.array([[5, 5]])], [(1, 0)], (12, 12))
     with pytest.raises(AssertionError):                 # two spots of one frame in one bin, flexlibrary.py:851-856
         O.greedy_tracking([np.array([[5, 5], [5, 5]])], [(0, 0)], (12, 12))
+
+
+def test_x87_header_on_host(tmp_path):
+    """csrc/fsq_x87.h (what the GPU kernel computes the pair distance with) compiled for the host: equal to the
+    long-double chain on 2 M vectors."""
+    import subprocess
+    from _util import ROOT
+    exe = str(tmp_path / "x87_check")
+    subprocess.check_call(["g++", "-O2", "-o", exe, os.path.join(ROOT, "tests", "x87_check.cpp")])
+    out = subprocess.check_output([exe]).decode()
+    assert "bad=0" in out, out
