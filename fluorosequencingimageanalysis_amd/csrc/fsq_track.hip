@@ -199,6 +199,86 @@ __global__ void __launch_bounds__(256) k8_track(const int32_t* __restrict__ hw, 
     if (t == 0) { status_out[fld] = 0; n_traces[fld] = S.nheads; n_disc[fld] = S.ndisc; }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// K9: luminosity-centroid tracking - Experiment.luminosity_centroid_particle_tracking with
+// next_frame_spot_by_luminosity_centroid, flexlibrary.py:1173-1317.  One thread follows one initial spot through the
+// frames of its field: the (2R+1)^2 window around the offset-corrected position of the last sighting (numpy slice
+// semantics, negative bounds wrap), its centre of mass (exact integer sums, one fp64 division per axis), Python-2
+// rounding, the Spot-fits-the-image test (flexlibrary.py:100-111), illumina_s_n of the 5x5 area (pflib.py:261-281, numpy's
+// summation order for 16 values) against the cut-off; below it the spot keeps the coordinates of its last sighting.
+__device__ __forceinline__ long trk_slice_bound(long v, long n) { if (v < 0) { v += n; if (v < 0) v = 0; } else if (v > n) v = n; return v; }
+__device__ __forceinline__ bool trk_spot_fits(long h, long w, int H, int W) { return 0 <= h - 2 && h + 2 < H && 0 <= w - 2 && w + 2 < W; }
+
+__device__ double trk_illumina_s_n(const uint16_t* __restrict__ img, int W, long h, long w)
+{
+    double op[16];
+    int t = 0;
+    unsigned mx = 0;
+    const uint16_t* base = img + (size_t)(h - 2) * W + (w - 2);
+    for (int a = 0; a < 5; a++)
+        for (int b = 0; b < 5; b++) { const unsigned v = base[(size_t)a * W + b]; mx = v > mx ? v : mx; }
+    for (int b = 0; b < 5; b++) op[t++] = (double)base[b];
+    for (int b = 0; b < 5; b++) op[t++] = (double)base[(size_t)4 * W + b];
+    for (int a = 1; a < 4; a++) { op[t++] = (double)base[(size_t)a * W]; op[t++] = (double)base[(size_t)a * W + 4]; }
+    double isum = 0.0;
+    for (int k = 0; k < 16; k++) isum += op[k];                     // integers: exact in any order
+    const double mean = isum / 16.0;
+    double rr[8];
+    for (int k = 0; k < 8; k++) { const double d0 = op[k] - mean, d1 = op[8 + k] - mean; rr[k] = d0 * d0 + d1 * d1; }
+    double res = ((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7]));   // numpy pairwise sum, n = 16
+    res = 0.0 + res;
+    return ((double)mx - mean) / __builtin_sqrt(res / 16.0);
+}
+
+__global__ void __launch_bounds__(256) k9_centroid_track(const uint16_t* __restrict__ frames, int n_fields, int F, int H, int W,
+                                                         const int32_t* __restrict__ init_hw, const int32_t* __restrict__ spot_field,
+                                                         long long n, int R, double s_n_cutoff, const long long* __restrict__ offsets,
+                                                         int32_t* __restrict__ out_hw, uint8_t* __restrict__ present,
+                                                         int32_t* __restrict__ n_errors)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int fld = spot_field[i];
+    long ph = init_hw[2 * i], pw = init_hw[2 * i + 1];
+    out_hw[(size_t)i * F * 2] = (int32_t)ph; out_hw[(size_t)i * F * 2 + 1] = (int32_t)pw;
+    present[(size_t)i * F] = 1;
+    const int D = 2 * R + 1;
+    bool failed = false;
+    for (int f = 1; f < F; f++) {
+        const uint16_t* img = frames + ((size_t)fld * F + f) * H * W;
+        const long oh = ph - (offsets ? (long)offsets[((size_t)fld * F + f) * 2] : 0);
+        const long ow = pw - (offsets ? (long)offsets[((size_t)fld * F + f) * 2 + 1] : 0);
+        const long h0 = trk_slice_bound(oh - R, H), h1 = trk_slice_bound(oh + R + 1, H);
+        const long w0 = trk_slice_bound(ow - R, W), w1 = trk_slice_bound(ow + R + 1, W);
+        bool found = false;
+        long nh = 0, nw = 0;
+        if (!failed && h1 - h0 == D && w1 - w0 == D) {
+            unsigned long long norm = 0, sh = 0, sw = 0;
+            for (int a = 0; a < D; a++)
+                for (int b = 0; b < D; b++) {
+                    const unsigned long long v = img[(size_t)(h0 + a) * W + (w0 + b)];
+                    norm += v; sh += v * (unsigned)a; sw += v * (unsigned)b;
+                }
+            if (norm == 0) failed = true;                               // NaN centroid: the reference raises ValueError
+            else {
+                const double ch = (double)sh / (double)norm, cw = (double)sw / (double)norm;
+                const long rh = trk_py2_round((ch + (double)oh) - (double)R), rw = trk_py2_round((cw + (double)ow) - (double)R);
+                if (trk_spot_fits(rh, rw, H, W)) {
+                    found = true; nh = rh; nw = rw;
+                    if (trk_illumina_s_n(img, W, rh, rw) < s_n_cutoff) {
+                        if (trk_spot_fits(ph, pw, H, W)) { nh = ph; nw = pw; } else found = false;
+                    }
+                }
+            }
+        }
+        present[(size_t)i * F + f] = found ? 1 : 0;
+        out_hw[((size_t)i * F + f) * 2] = found ? (int32_t)nh : -1;
+        out_hw[((size_t)i * F + f) * 2 + 1] = found ? (int32_t)nw : -1;
+        if (found) { ph = nh; pw = nw; }
+    }
+    if (failed) atomicAdd(n_errors, 1);
+}
+
 __global__ void kx87check(const double* __restrict__ dh, const double* __restrict__ dw, long long n, double* __restrict__ out)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -229,6 +309,23 @@ extern "C" int fsq_greedy_tracking(const int32_t* d_hw, const int32_t* d_field_s
     hipLaunchKernelGGL(k8_track, dim3(n_fields), dim3(256), 0, s, d_hw, d_field_start, d_counts, d_offsets, n_frames, H, W,
                        candidate_radius, spot_radius, d_prev, d_next, d_kept, d_traces, d_n_traces, d_n_discarded, d_status,
                        (int32_t*)d_workspace, (unsigned char*)d_workspace + (size_t)n_fields * 2 * H * W * 4, (int)pair_cap);
+    FSQ_HIP_CHECK(hipGetLastError());
+    return FSQ_OK;
+}
+
+extern "C" int fsq_centroid_tracking(const uint16_t* d_frames, int n_fields, int n_frames, int H, int W, const int32_t* d_init_hw,
+                                     const int32_t* d_spot_field, int64_t n, int search_radius, double s_n_cutoff,
+                                     const int64_t* d_offsets, int32_t* d_out_hw, uint8_t* d_present, int32_t* d_n_errors,
+                                     void* stream)
+{
+    if (n_fields < 1 || n_frames < 1 || H < 1 || W < 1 || n < 0 || search_radius < 0) return FSQ_EINVAL;
+    if (!d_frames || !d_n_errors || (n > 0 && (!d_init_hw || !d_spot_field || !d_out_hw || !d_present))) return FSQ_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    FSQ_HIP_CHECK(hipMemsetAsync(d_n_errors, 0, sizeof(int32_t), s));
+    if (n > 0)
+        hipLaunchKernelGGL(k9_centroid_track, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_frames, n_fields, n_frames, H, W,
+                           d_init_hw, d_spot_field, (long long)n, search_radius, s_n_cutoff, (const long long*)d_offsets, d_out_hw,
+                           d_present, d_n_errors);
     FSQ_HIP_CHECK(hipGetLastError());
     return FSQ_OK;
 }

@@ -87,8 +87,89 @@ def track_fields(fields, offsets, frame_shape, candidate_radius=2, spot_radius=0
     return out
 
 
+def centroid_track_fields(frames, init_hw, spot_field=None, search_radius=3, s_n_cutoff=3.0, offsets=None, device=None):
+    """Luminosity-centroid tracking of many spots in many fields in one launch (fsq_centroid_tracking).
+
+    frames uint16[n_fields, F, H, W] (or [F, H, W] for one field); init_hw int[n, 2]; spot_field int[n] (default: all in
+    field 0); offsets whole-pixel (d_h, d_w)[n_fields, F, 2] or None.  -> (hw int32[n, F, 2], present bool[n, F]);
+    raises ValueError where the reference does (a search window that sums to zero)."""
+    torch = _engine._torch()
+    dev = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
+    fr = _engine.as_u16_fields(frames)
+    if fr.ndim == 3:
+        fr = fr[None]
+    if fr.ndim != 4:
+        raise ValueError("frames must have shape (n_fields, F, H, W)")
+    n_fields, F, H, W = fr.shape
+    hw = np.ascontiguousarray(np.asarray(init_hw, dtype=np.int32).reshape(-1, 2))
+    n = len(hw)
+    sf = np.zeros(n, np.int32) if spot_field is None else np.ascontiguousarray(spot_field, dtype=np.int32)
+    if len(sf) != n or (n and (sf.min() < 0 or sf.max() >= n_fields)):
+        raise ValueError("spot_field must name a field for every spot")
+    d_off = None
+    if offsets is not None:
+        off = np.asarray(offsets)
+        if not np.array_equal(off, np.rint(off)):
+            raise TypeError("slice indices must be integers")       # what the reference's image slicing raises (:1223)
+        d_off = torch.from_numpy(np.ascontiguousarray(off.astype(np.int64).reshape(n_fields, F, 2))).to(dev)
+    d_fr = _engine.to_device_u16(fr, dev)
+    d_hw, d_sf = torch.from_numpy(hw).to(dev), torch.from_numpy(sf).to(dev)
+    d_out = torch.empty((max(n, 1), F, 2), dtype=torch.int32, device=dev)
+    d_pres = torch.empty((max(n, 1), F), dtype=torch.uint8, device=dev)
+    d_err = torch.zeros(1, dtype=torch.int32, device=dev)
+    rc = N.lib().fsq_centroid_tracking(d_fr.data_ptr(), n_fields, F, H, W, d_hw.data_ptr(), d_sf.data_ptr(), n, int(search_radius),
+                                       float(s_n_cutoff), d_off.data_ptr() if d_off is not None else None, d_out.data_ptr(),
+                                       d_pres.data_ptr(), d_err.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    N.check(rc, "fsq_centroid_tracking")
+    if int(d_err.item()):
+        raise ValueError("cannot convert float NaN to integer")     # int(round(nan)) of an all-zero window's centroid
+    return d_out[:n].cpu().numpy(), d_pres[:n].cpu().numpy().astype(bool)
+
+
+class Spot(object):
+    """A square of pixels in an image: the reference's Spot as far as tracking needs it (flexlibrary.py:74-112):
+    `parent_Image` (anything with an `.image` array), integer centre (h, w), odd size, optional gaussian_fit tuple."""
+
+    def __init__(self, parent_Image, h, w, size, gaussian_fit=None):
+        self.parent_Image = parent_Image
+        if size % 2 == 0:
+            raise AttributeError("Spot.size must be odd.")
+        self.size = size
+        r, shape = (size - 1) // 2, parent_Image.image.shape
+        if not (0 <= h - r and h + r < shape[0] and 0 <= w - r and w + r < shape[1]):
+            if (gaussian_fit is None or not (r <= gaussian_fit[0] < shape[0] - r) and (r <= gaussian_fit[1] < shape[1] - r)):
+                raise AttributeError("Spot area of size " + str(size) + " at " + str((h, w)) + " with gaussian_fit " +
+                                     str(gaussian_fit) + " does not fit into parent_Image.image.shape of " + str(shape))
+        self.h, self.w = h, w
+        self.gaussian_fit = gaussian_fit
+
+
 class Experiment(object):
     """The static tracking helpers of the reference's Experiment class."""
+
+    @staticmethod
+    def luminosity_centroid_particle_tracking(frames, initial_spots, search_radius=3, s_n_cutoff=3.0, offsets=None):
+        """Follow Spots through frames by the centroid of pixel luminosity.  flexlibrary.py:1262-1317.
+        frames: Images (objects with `.image`) of one shape; initial_spots: Spots of frames[0] (size 5).
+        Returns one list per spot: its Spot in every frame, or None."""
+        frames = list(frames)
+        if not all(spot.parent_Image is frames[0] for spot in initial_spots):
+            raise ValueError("All initial_spots must be in frames[0].")
+        initial_spots = list(initial_spots)
+        if not initial_spots:
+            return []
+        if any(s.size != 5 for s in initial_spots):
+            raise NotImplementedError("luminosity-centroid tracking on the GPU handles Spots of size 5")
+        stack = np.stack([np.asarray(f.image) for f in frames])
+        off = None if offsets is None else np.asarray([(o[0], o[1]) for o in offsets])[None]
+        hw, present = centroid_track_fields(stack, [(s.h, s.w) for s in initial_spots], None, search_radius, s_n_cutoff, off)
+        tracks = []
+        for spot, row, pr in zip(initial_spots, hw, present):
+            tr = [spot]
+            for f in range(1, len(frames)):
+                tr.append(Spot(frames[f], int(row[f][0]), int(row[f][1]), spot.size) if pr[f] else None)
+            tracks.append(tr)
+        return tracks
 
     @staticmethod
     def accumulate_offsets(offsets):

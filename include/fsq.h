@@ -229,6 +229,22 @@ int fsq_greedy_tracking(const int32_t* d_hw, const int32_t* d_field_start, const
                         int32_t* d_prev, int32_t* d_next, uint8_t* d_kept, int32_t* d_traces, int32_t* d_n_traces,
                         int32_t* d_n_discarded, int32_t* d_status, int64_t pair_cap, void* d_workspace,
                         int64_t workspace_bytes, void* stream);
+/*
+ * Luminosity-centroid tracking: Experiment.luminosity_centroid_particle_tracking with
+ * next_frame_spot_by_luminosity_centroid, flexlibrary.py:1173-1317, for Spots of size 5.
+ *   d_frames      uint16[n_fields][n_frames][H][W]
+ *   d_init_hw     int32[n][2]   the initial Spots (h, w) in frame 0 of their field; d_spot_field int32[n] their field
+ *   d_offsets     int64[n_fields][n_frames][2] or NULL: offsets[f] is taken off the last sighting's coordinates when the
+ *                 spot is looked for in frame f (whole pixels: the reference slices the image with them)
+ *   d_out_hw      int32[n][n_frames][2] out: the spot's (h, w) in every frame, (-1, -1) where the reference has None
+ *   d_present     uint8[n][n_frames] out
+ *   d_n_errors    int32[1] out: spots whose search window summed to zero (the reference raises ValueError there:
+ *                 int(round(nan))); their later frames are reported as absent
+ * Enqueue only.
+ */
+int fsq_centroid_tracking(const uint16_t* d_frames, int n_fields, int n_frames, int H, int W, const int32_t* d_init_hw,
+                          const int32_t* d_spot_field, int64_t n, int search_radius, double s_n_cutoff,
+                          const int64_t* d_offsets, int32_t* d_out_hw, uint8_t* d_present, int32_t* d_n_errors, void* stream);
 /* fsq_selftest_dnrm2: the tracking kernel's pair distance (OpenBLAS dnrm2 in x87 extended precision, restated in
  * integer arithmetic, csrc/fsq_x87.h) for caller-supplied displacement vectors; d_out[i] = dnrm2((d_dh[i], d_dw[i])). */
 int fsq_selftest_dnrm2(const double* d_dh, const double* d_dw, int64_t n, double* d_out, void* stream);

@@ -164,3 +164,63 @@ int fsq_o_greedy_tracking(int n_frames, const int32_t* counts, const int32_t* hw
     free(bins); free(cache); free(pairs); free(frame_of); free(cell_of); free(cum); free(start);
     return rc;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Experiment.luminosity_centroid_particle_tracking / next_frame_spot_by_luminosity_centroid,
+ * flexlibrary.py:1173-1317, for Spots of size 5 and integer offsets (a non-integer offset makes the reference's
+ * image slicing raise TypeError under the numpy of the build container).
+ * frames uint16[F][H][W]; init_hw int32[n][2]; offsets int64[F][2] (offsets[f] is applied between frame f-1 and f;
+ * NULL = all zero).  out_hw int32[n][F][2], present uint8[n][F] (0 = None).
+ * Returns 0, or -1 for the reference's ValueError (all-zero search window: centre of mass is NaN, int(round(nan))).
+ */
+static long slice_bound(long v, long n) { if (v < 0) { v += n; if (v < 0) v = 0; } else if (v > n) v = n; return v; }
+
+static int spot_fits(long h, long w, int size, int H, int W)               /* Spot.__init__, flexlibrary.py:100-111 */
+{
+    const long r = (size - 1) / 2;
+    return 0 <= h - r && h + r < H && 0 <= w - r && w + r < W;
+}
+
+int fsq_o_centroid_tracking(const uint16_t* frames, int F, int H, int W, const int32_t* init_hw, int n, int size,
+                            int search_radius, double s_n_cutoff, const int64_t* offsets, int32_t* out_hw, uint8_t* present)
+{
+    if (size != 5 || search_radius < 0) return -2;
+    const int R = search_radius, D = 2 * R + 1;
+    for (int i = 0; i < n; i++) {
+        long ph = init_hw[2 * i], pw = init_hw[2 * i + 1];                   /* prior_frame_spot */
+        out_hw[((size_t)i * F) * 2] = (int32_t)ph; out_hw[((size_t)i * F) * 2 + 1] = (int32_t)pw;
+        present[(size_t)i * F] = 1;
+        for (int f = 1; f < F; f++) {
+            const uint16_t* img = frames + (size_t)f * H * W;
+            const long oh = ph - (offsets ? offsets[2 * f] : 0), ow = pw - (offsets ? offsets[2 * f + 1] : 0);
+            /* numpy slice image[oh-R : oh+R+1, ow-R : ow+R+1] (negative bounds wrap, flexlibrary.py:1223-1226) */
+            const long h0 = slice_bound(oh - R, H), h1 = slice_bound(oh + R + 1, H);
+            const long w0 = slice_bound(ow - R, W), w1 = slice_bound(ow + R + 1, W);
+            int found = 0; long nh = 0, nw = 0;
+            if (h1 - h0 == D && w1 - w0 == D) {
+                uint64_t norm = 0; double sh = 0.0, sw = 0.0;                 /* scipy.ndimage.center_of_mass: exact sums */
+                for (int a = 0; a < D; a++)
+                    for (int b = 0; b < D; b++) {
+                        const uint16_t v = img[(size_t)(h0 + a) * W + (w0 + b)];
+                        norm += v; sh += (double)v * (double)a; sw += (double)v * (double)b;
+                    }
+                if (norm == 0) return -1;
+                const double ch = sh / (double)norm, cw = sw / (double)norm;
+                const long rh = py2_round((ch + (double)oh) - (double)R), rw = py2_round((cw + (double)ow) - (double)R);
+                if (spot_fits(rh, rw, size, H, W)) {
+                    int64_t roi[25];
+                    for (int a = 0; a < 5; a++) for (int b = 0; b < 5; b++) roi[a * 5 + b] = img[(size_t)(rh - 2 + a) * W + (rw - 2 + b)];
+                    found = 1; nh = rh; nw = rw;
+                    if (fsq_o_illumina_s_n(roi) < s_n_cutoff) {               /* :1248-1259: same coordinates as the prior spot */
+                        if (spot_fits(ph, pw, size, H, W)) { nh = ph; nw = pw; } else found = 0;
+                    }
+                }
+            }
+            present[(size_t)i * F + f] = (uint8_t)found;
+            out_hw[((size_t)i * F + f) * 2] = found ? (int32_t)nh : -1;
+            out_hw[((size_t)i * F + f) * 2 + 1] = found ? (int32_t)nw : -1;
+            if (found) { ph = nh; pw = nw; }
+        }
+    }
+    return 0;
+}

@@ -9,7 +9,7 @@ fluorosequencingimageanalysis_amd/synth.py.  The .npz files hold DATA only
 
 Usage (about 4 minutes on 8 cores):
   NPY_DISABLE_CPU_FEATURES="AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL AVX512_SPR" \
-      python oracle/gen_golden.py [--only fields|reg|kat|phot|degen|textbook|io|track]
+      python oracle/gen_golden.py [--only fields|reg|kat|phot|degen|textbook|io|track|centroid]
 
 Golden sets: G1 per-ROI fits, G2 candidate lists, G3 full
 find_peptides tables, G4 phase_correlate tuples, G5 known-answer tests.
@@ -408,6 +408,57 @@ def gen_tracking():
     np.savez_compressed(os.path.join(GOLD, "tracking.npz"), **out)
 
 
+def centroid_cases():
+    """name -> (frames uint16[F,H,W], init_hw, offsets int[F,2] or None, search_radius, s_n_cutoff)."""
+    import oracle as O
+    R = _ref()
+    cases = {}
+    frames, _ = synth.make_cycle_stack(41, n_cycles=7, shape=(160, 160), n_spots=60, max_drift=2.5, dropout=0.2)
+    rows, fits, keep, key = O.find_peptides(frames[0], n_threads=os.cpu_count())
+    offs = [(0, 0)]
+    for f in range(1, len(frames)):
+        d_h, d_w, _, _ = R.pc.phase_correlate(frames[f - 1], frames[f], upsample_factor=1)
+        offs.append((int(d_h), int(d_w)))
+    cases["stack160_registered"] = (frames, np.asarray(key, np.int32), np.array(offs, np.int64), 3, 3.0)
+    cases["stack160_no_offsets_r2"] = (frames, np.asarray(key, np.int32), None, 2, 3.0)
+    cases["stack160_strict"] = (frames, np.asarray(key, np.int32), np.array(offs, np.int64), 3, 12.0)
+    # spots along the borders and in the corners of a noisy frame, big drifts
+    rng = np.random.default_rng(9)
+    noisy = rng.integers(90, 400, (5, 48, 48)).astype(np.uint16)
+    noisy[:, 20:23, 20:23] += 3000
+    edge = np.array([(2, 2), (2, 45), (45, 2), (45, 45), (3, 24), (24, 3), (44, 24), (24, 44), (21, 21), (5, 5), (10, 40)], np.int32)
+    cases["borders"] = (noisy, edge, np.array([(0, 0), (2, -3), (-4, 1), (0, 5), (-6, -6)], np.int64), 3, 3.0)
+    return cases
+
+
+def gen_centroid():
+    """N4 goldens: Experiment.luminosity_centroid_particle_tracking of the reference (flexlibrary.py:1262-1317)."""
+    import refload
+    ref = refload.load_flexlibrary(_ref())
+    fl = ref.fl
+
+    class Img(object):
+        def __init__(self, a):
+            self.image = a
+    out = {"names": []}
+    for name, (frames, init_hw, offsets, sr, cut) in centroid_cases().items():
+        imgs = [Img(f) for f in frames]
+        spots = [fl.Spot(imgs[0], int(h), int(w), 5) for h, w in init_hw]
+        tracks = fl.Experiment.luminosity_centroid_particle_tracking(
+            imgs, spots, search_radius=sr, s_n_cutoff=cut,
+            offsets=None if offsets is None else [(int(a), int(b)) for a, b in offsets])
+        hw = np.array([[(-1, -1) if s is None else (s.h, s.w) for s in tr] for tr in tracks], dtype=np.int32)
+        out["names"].append(name)
+        out[name + "_frames"] = frames
+        out[name + "_init"] = np.asarray(init_hw, np.int32)
+        out[name + "_offsets"] = np.zeros((0, 2), np.int64) if offsets is None else np.asarray(offsets, np.int64)
+        out[name + "_params"] = np.array([sr, cut])
+        out[name + "_hw"] = hw
+        print(name, "spots", len(spots), "present fraction", float((hw[:, :, 0] >= 0).mean()), flush=True)
+    out["names"] = np.array(out["names"])
+    np.savez_compressed(os.path.join(GOLD, "centroid_tracking.npz"), **out)
+
+
 def gen_io():
     """On-disk formats: the reference's own save_psfs_csv / save_psfs_pkl / _psfs_filename on its own
     find_peptides result for field f5 (pflib.py:569-711).  The CSV text is what the reference writes under THIS
@@ -457,6 +508,8 @@ def main():
             gen_fields(pool)
     if a.only in ("", "track"):
         gen_tracking()
+    if a.only in ("", "centroid"):
+        gen_centroid()
     if a.only in ("", "io"):
         gen_io()
     if a.only in ("", "degen"):

@@ -192,3 +192,25 @@ def greedy_tracking(frame_hw, offsets, shape, candidate_radius=2, spot_radius=0.
     if rc < 0:
         raise RuntimeError("oracle greedy_tracking error %d" % rc)
     return traces[:nt.value].copy(), nd.value, prev[:n].copy(), nxt[:n].copy(), kept[:n].astype(bool)
+
+
+def centroid_tracking(frames, init_hw, search_radius=3, s_n_cutoff=3.0, offsets=None, size=5):
+    """Experiment.luminosity_centroid_particle_tracking (flexlibrary.py:1262-1317) for one field:
+    frames uint16[F, H, W], init_hw int[n, 2], offsets int[F, 2] or None -> (hw int32[n, F, 2], present bool[n, F])."""
+    frames = np.ascontiguousarray(frames, dtype=np.uint16)
+    F, H, W = frames.shape
+    hw = np.ascontiguousarray(np.asarray(init_hw, dtype=np.int32).reshape(-1, 2))
+    n = len(hw)
+    off = None if offsets is None else np.ascontiguousarray(np.asarray(offsets, dtype=np.int64).reshape(F, 2))
+    out = np.zeros((n, F, 2), np.int32)
+    present = np.zeros((n, F), np.uint8)
+    L = lib()
+    L.fsq_o_centroid_tracking.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    rc = L.fsq_o_centroid_tracking(_p(frames), F, H, W, _p(hw), n, int(size), int(search_radius), float(s_n_cutoff),
+                                   None if off is None else _p(off), _p(out), _p(present))
+    if rc == -1:
+        raise ValueError("cannot convert float NaN to integer")
+    if rc < 0:
+        raise NotImplementedError("oracle centroid_tracking: only Spot size 5")
+    return out, present.astype(bool)

@@ -107,5 +107,8 @@ def load_flexlibrary(ref=None):
     libm.round.restype = ctypes.c_double
     libm.round.argtypes = [ctypes.c_double]
     # Python-2 round() (half away from zero) for the bin coordinates of the tracking code (flexlibrary.py:850, 880)
-    ref.fl = load("flexlibrary", "flexlibrary.py", inject={"round": lambda x: libm.round(float(x))})
+    # (Python 2: `/` between ints is floor division - Spot's (size - 1) / 2 radius feeds numpy slices)
+    ref.fl = load("flexlibrary", "flexlibrary.py",
+                  [("(self.size - 1) / 2", "(self.size - 1) // 2"), ("(size - 1) / 2", "(size - 1) // 2")],
+                  inject={"round": lambda x: libm.round(float(x))})
     return ref

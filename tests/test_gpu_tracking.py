@@ -4,7 +4,7 @@ random layouts; the integer restatement of the x87 dnrm2 distance against the or
 import numpy as np
 import pytest
 
-from test_tracking import load_cases
+from test_tracking import load_cases, load_centroid_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -111,3 +111,46 @@ def test_x87_dnrm2_restatement(env):
     exp = np.array([L.fsq_o_euclid2(a, b) for a, b in zip(dh, dw)])
     assert np.array_equal(got.view(np.uint64), exp.view(np.uint64))
     assert (exp != np.sqrt(dh * dh + dw * dw)).mean() > 0.05           # ...and plain double arithmetic is not the same
+
+
+@pytest.mark.parametrize("case", list(load_centroid_cases()), ids=lambda c: c[0])
+def test_centroid_tracking_equals_reference(env, case):
+    """N4: luminosity-centroid tracking == the reference's recorded tracks (tests/golden/centroid_tracking.npz)."""
+    torch, N, fl, O = env
+    name, frames, init, offsets, sr, cut, hw = case
+    got, present = fl.centroid_track_fields(frames, init, None, sr, cut, None if offsets is None else offsets[None])
+    assert np.array_equal(got, hw) and np.array_equal(present, hw[:, :, 0] >= 0)
+
+
+def test_centroid_tracking_batch_and_objects(env):
+    torch, N, fl, O = env
+    cases = {c[0]: c for c in load_centroid_cases()}
+    name, frames, init, offsets, sr, cut, hw = cases["stack160_registered"]
+    rng = np.random.default_rng(3)
+    stack = np.stack([frames, frames[::-1].copy(), np.roll(frames, 5, axis=1)])        # three different fields
+    offs = np.stack([offsets, rng.integers(-3, 4, offsets.shape), np.zeros_like(offsets)])
+    offs[:, 0] = 0
+    pts = np.concatenate([init, init, init])
+    fld = np.repeat(np.arange(3), len(init)).astype(np.int32)
+    got, present = fl.centroid_track_fields(stack, pts, fld, sr, cut, offs)
+    for k in range(3):
+        exp, ep = O.centroid_tracking(stack[k], init, sr, cut, offs[k])
+        assert np.array_equal(got[fld == k], exp) and np.array_equal(present[fld == k], ep)
+
+    class Img(object):
+        def __init__(self, a):
+            self.image = a
+    imgs = [Img(f) for f in frames]
+    spots = [fl.Spot(imgs[0], int(h), int(w), 5) for h, w in init]
+    tracks = fl.Experiment.luminosity_centroid_particle_tracking(imgs, spots, offsets=[tuple(int(x) for x in o) for o in offsets])
+    assert len(tracks) == len(init)
+    got_hw = np.array([[(-1, -1) if s is None else (s.h, s.w) for s in tr] for tr in tracks])
+    assert np.array_equal(got_hw, hw)
+    with pytest.raises(ValueError):
+        fl.Experiment.luminosity_centroid_particle_tracking(imgs[1:], spots)
+    with pytest.raises(TypeError):
+        fl.centroid_track_fields(frames, init, None, 3, 3.0, offsets[None] + 0.5)
+    with pytest.raises(ValueError):
+        fl.centroid_track_fields(np.zeros((2, 16, 16), np.uint16), [(8, 8)])
+    with pytest.raises(AttributeError):
+        fl.Spot(imgs[0], 1, 5, 5)

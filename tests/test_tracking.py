@@ -74,3 +74,31 @@ def test_x87_header_on_host(tmp_path):
     subprocess.check_call(["g++", "-O2", "-o", exe, os.path.join(ROOT, "tests", "x87_check.cpp")])
     out = subprocess.check_output([exe]).decode()
     assert "bad=0" in out, out
+
+
+def load_centroid_cases():
+    g = np.load(os.path.join(GOLD, "centroid_tracking.npz"))
+    for name in g["names"]:
+        name = str(name)
+        off = g[name + "_offsets"]
+        yield (name, g[name + "_frames"], g[name + "_init"], None if len(off) == 0 else off, int(g[name + "_params"][0]),
+               float(g[name + "_params"][1]), g[name + "_hw"])
+
+
+@pytest.mark.parametrize("case", list(load_centroid_cases()), ids=lambda c: c[0])
+def test_oracle_centroid_tracking_equals_reference(case):
+    """N4: Experiment.luminosity_centroid_particle_tracking (flexlibrary.py:1262-1317) as recorded from the reference
+    (oracle/gen_golden.py --only centroid): every spot's position, or None, in every frame."""
+    name, frames, init, offsets, sr, cut, hw = case
+    got, present = O.centroid_tracking(frames, init, sr, cut, offsets)
+    assert np.array_equal(got, hw)
+    assert np.array_equal(present, hw[:, :, 0] >= 0)
+
+
+def test_centroid_goldens_cover_the_cases():
+    cases = {c[0]: c for c in load_centroid_cases()}
+    assert (cases["borders"][6][:, 1:, 0] < 0).any() and (cases["borders"][6][:, 1:, 0] >= 0).any()
+    a, b = cases["stack160_registered"][6], cases["stack160_strict"][6]
+    assert not np.array_equal(a, b)                     # the s_n cut-off branch (same coordinates as the prior spot) is taken
+    with pytest.raises(ValueError):                     # all-zero search window: centre of mass is NaN
+        O.centroid_tracking(np.zeros((2, 16, 16), np.uint16), [(8, 8)])
