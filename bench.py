@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=2, help="lanes pipeline: shares of the batch worked side by side")
     ap.add_argument("--depth", type=int, default=16, help="stream pipeline: batches in flight at most")
     ap.add_argument("--inject-below", type=int, default=None, help="stream pipeline: submit the next batch once fewer fits are alive")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3),
+                    help="2: BASELINE configs[1], detect + fit + consolidate (the headline); 3: the registration step of configs[2] "
+                         "(phase correlation of consecutive cycle frames, upsample_factor 20) - pairs/s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the H2D-inclusive and dict-materialising side measurements")
     a = ap.parse_args()
@@ -87,6 +90,8 @@ def main():
     from fluorosequencingimageanalysis_amd import engine as E
     from fluorosequencingimageanalysis_amd import pflib
 
+    if a.config == 3:
+        return bench_registration(a, torch, dist, D, E, N)
     # synthetic fields first: the worker pool forks before this process has touched the GPU or opened a communicator
     shape = (a.size, a.size)
     env_rank = int(os.environ.get("RANK", "0"))
@@ -164,6 +169,64 @@ def main():
             n_thr = min(16, len(os.sched_getaffinity(0)))     # the box's CPU share for one GPU
             out["cpu_baseline"] = cpu_baseline(imgs, cand, counts, offsets, n_thr)
         print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+REG_BYTES_PER_PX = 2 * (2 + 8) + 2 * 4 * 8 + (16 + 16 + 8) + 4 * 8 + 8 + 2 * 8      # = 180
+# fp64 real-transform registration, per pixel of a pair: 2 images uint16 -> float64 (2 B in, 8 B out each); two forward
+# real-to-complex FFTs of two passes each (8 B in + 8 B out per pass: a half spectrum is 8 B per pixel); cross-power
+# (two half spectra in, one out); the inverse transform (two passes); the peak search (8 B); the upsampled DFT's one
+# read of both half spectra.  = 180 B per pixel = 45 MiB per 512x512 pair ("halve with R2C").
+
+
+def bench_registration(a, torch, dist, D, E, N):
+    """configs[2]'s registration step: consecutive cycle frames of channel 0 registered at upsample_factor 20
+    (SequenceExperiment.offsets_from_frames, flexlibrary.py:1717-1741): 32 fields x 7 pairs of 512x512 uint16 frames per
+    step, resident in HBM.  value = pairs per second."""
+    from fluorosequencingimageanalysis_amd import phase_correlate as PC
+    from fluorosequencingimageanalysis_amd import synth
+    rank, world, local = D.init_from_env()
+    local = local % torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    H = W = a.size
+    stacks = [synth.make_cycle_stack(100 + 7 * rank + f, n_cycles=8, shape=(H, W), n_spots=a.spots)[0] for f in range(4)]
+    ref = np.tile(np.concatenate([s_[:-1] for s_ in stacks]), (8, 1, 1))
+    reg = np.tile(np.concatenate([s_[1:] for s_ in stacks]), (8, 1, 1))
+    n = len(ref)
+    d_ref, d_reg = E.to_device_u16(ref), E.to_device_u16(reg)
+    R = PC.Registrar(n, H, W, 20, N.DTYPE_U16)
+    out = R.register(d_ref, d_reg)
+    for _ in range(a.warmup):
+        R.register(d_ref, d_reg, out)
+    _barrier(torch, dist, world)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(a.steps):
+        R.register(d_ref, d_reg, out)
+    ev1.record()
+    _barrier(torch, dist, world)
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+    if rank == 0:
+        ms = ev0.elapsed_time(ev1) / a.steps
+        by = REG_BYTES_PER_PX * H * W * n
+        print(json.dumps({
+            "metric": "registration_pairs_per_sec", "value": n * world * a.steps / dt, "unit": "pairs/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[2] registration step: %d pairs of consecutive %dx%d uint16 cycle frames per GPU and "
+                                   "step (32 fields x 7 pairs), phase correlation at upsample_factor 20" % (n, H, W),
+                       "pairs_per_gpu": n, "parallelism": "pairs sharded over %d rank(s), no exchange" % world},
+            "roofline": {"bound": "hbm", "kernel": "fsq_phase_correlate as one unit (rocFFT real transforms + cross-power, peak, "
+                                                   "upsampled-DFT kernels)", "achieved": by / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                         "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                         "algorithmic_bytes_per_pair": REG_BYTES_PER_PX * H * W, "launch_ms": ms}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -311,4 +374,14 @@ def extras(a, torch, E, N, pflib, imgs, d_img, prm, dev):
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as e:      # noqa: BLE001
+        if isinstance(e, SystemExit) and not e.code:
+            raise
+        # a failed rank must not leave its peers waiting in a collective: report and leave without the interpreter's
+        # orderly shutdown (which would block in the process group's destructor); torchrun then ends the job non-zero
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)

@@ -7,23 +7,60 @@ from . import _native as N
 from . import engine as _engine
 
 
+class Registrar:
+    """Re-usable workspace for registering batches of n pairs of H x W images (fsq_phase_correlate).
+    Inputs are device tensors: uint16 camera frames as they sit in HBM (int16-typed torch tensors holding the same
+    bytes, engine.to_device_u16) or float64.  register() only enqueues on the current stream."""
+
+    def __init__(self, n_pairs, H, W, upsample_factor=1, dtype=N.DTYPE_U16, device=None):
+        torch = _engine._torch()
+        self.torch = torch
+        self.dev = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
+        self.n, self.H, self.W, self.uf, self.dtype = int(n_pairs), int(H), int(W), int(upsample_factor), int(dtype)
+        self.L = N.lib()
+        self.ws = None
+        self.ws_stream = None
+
+    def _workspace(self, stream):
+        if self.ws is None or self.ws_stream != stream:        # (plans and their work areas are per stream)
+            nbytes = self.L.fsq_phase_correlate_workspace_bytes(self.n, self.H, self.W, self.uf, self.dtype, stream)
+            N.check(min(nbytes, 0), "fsq_phase_correlate_workspace_bytes")
+            self.ws = self.torch.empty(nbytes, dtype=self.torch.uint8, device=self.dev)
+            self.ws_stream = stream
+        return self.ws
+
+    def register(self, d_ref, d_reg, out=None):
+        """-> float64[n, 4] device tensor (row_shift, col_shift, error, diffphase), enqueued on the current stream."""
+        torch = self.torch
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        ws = self._workspace(stream)
+        if out is None:
+            out = torch.empty((self.n, 4), dtype=torch.float64, device=self.dev)
+        rc = self.L.fsq_phase_correlate(d_ref.data_ptr(), d_reg.data_ptr(), self.dtype, self.n, self.H, self.W, self.uf,
+                                        out.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+        N.check(rc, "fsq_phase_correlate")
+        return out
+
+
 def phase_correlate_batch(ref_images, reg_images, upsample_factor=1):
-    """Register a stack of pairs float64[n, H, W] -> float64[n, 4] = (row_shift, col_shift, error, diffphase)."""
+    """Register a stack of pairs [n, H, W] -> float64[n, 4] = (row_shift, col_shift, error, diffphase).
+    uint16 stacks are uploaded and transformed as they are; anything else goes through float64 like the reference's
+    np.array(image, dtype=np.float64) (phase_correlate.py:63-64)."""
     torch = _engine._torch()
-    ref = np.ascontiguousarray(ref_images, dtype=np.float64)
-    reg = np.ascontiguousarray(reg_images, dtype=np.float64)
+    ref, reg = np.asarray(ref_images), np.asarray(reg_images)
     if ref.shape != reg.shape:
         raise ValueError("Error: images must be same size for phase_correlate")
     if ref.ndim != 3:
         raise ValueError("Error: phase_correlate only supports 2D images")
     n, H, W = ref.shape
-    d_ref = torch.from_numpy(ref).cuda()
-    d_reg = torch.from_numpy(reg).cuda()
-    out = torch.empty((n, 4), dtype=torch.float64, device=d_ref.device)
-    rc = N.lib().fsq_phase_correlate(d_ref.data_ptr(), d_reg.data_ptr(), n, H, W, int(upsample_factor), out.data_ptr(),
-                                     torch.cuda.current_stream().cuda_stream)
-    N.check(rc, "fsq_phase_correlate")
-    return out.cpu().numpy()
+    if ref.dtype == np.uint16 and reg.dtype == np.uint16:
+        dtype = N.DTYPE_U16
+        d_ref, d_reg = _engine.to_device_u16(ref), _engine.to_device_u16(reg)
+    else:
+        dtype = N.DTYPE_F64
+        d_ref = torch.from_numpy(np.ascontiguousarray(ref, dtype=np.float64)).cuda()
+        d_reg = torch.from_numpy(np.ascontiguousarray(reg, dtype=np.float64)).cuda()
+    return Registrar(n, H, W, upsample_factor, dtype).register(d_ref, d_reg).cpu().numpy()
 
 
 def phase_correlate(ref_image, reg_image, upsample_factor=1):
@@ -48,7 +85,9 @@ def offsets_from_frames(alignment_frames, upsample_factor=20):
     (flexlibrary.py:1717-1741) - offsets[0] = (0, 0) and offsets[f + 1] = phase_correlate(frame f, frame f + 1)[:2],
     each relative to the PREVIOUS frame - with all pairs registered in one batched GPU call.
     `alignment_frames`: sequence of 2-D images (or objects with an `.image` attribute, like flexlibrary.Image)."""
-    imgs = [np.asarray(getattr(f, "image", f), dtype=np.float64) for f in alignment_frames]
+    imgs = [np.asarray(getattr(f, "image", f)) for f in alignment_frames]
+    if not all(im.dtype == np.uint16 for im in imgs):
+        imgs = [np.asarray(im, dtype=np.float64) for im in imgs]
     offsets = [(0, 0) for _ in imgs]
     if len(imgs) < 2:
         return offsets

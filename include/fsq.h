@@ -183,12 +183,20 @@ int fsq_kept_rows(const FsqRow* d_rows, const int32_t* d_keep, const int32_t* d_
 int fsq_fit_images(const FsqRow* d_rows, const int32_t* d_idx, int64_t n, double* d_fit_img, void* stream);
 
 /*
- * Registration of n_pairs image pairs (double[n_pairs][H][W] each), out4 = (row_shift, col_shift,
- * error, diffphase) per pair, double[n_pairs][4].  Synchronises the stream (rocFFT plan + small
- * host-side control).
+ * Registration of n_pairs image pairs: out4 = (row_shift, col_shift, error, diffphase) per pair, double[n_pairs][4]
+ * (phase_correlate.phase_correlate, phase_correlate.py:11-134; the reference converts whatever it is handed to float64,
+ * :63-64).
+ *   d_ref, d_reg  [n_pairs][H][W] of `dtype`: FSQ_DTYPE_F64 (double) or FSQ_DTYPE_U16 (camera frames as they sit in HBM)
+ *   d_workspace   fsq_phase_correlate_workspace_bytes(...) bytes for the same arguments (spectra, FFT work areas, peaks)
+ * Enqueue only: FFTs (rocFFT real-to-complex / complex-to-real, fp64), the peak search, the upsampled matrix-multiply DFT
+ * and the error / phase arithmetic all run on `stream`; nothing is allocated and the host never waits.
+ * FFT plans are cached per (shape, batch, device, stream); calls are serialised on an internal lock while they enqueue.
  */
-int fsq_phase_correlate(const double* d_ref, const double* d_reg, int n_pairs, int H, int W,
-                        int upsample_factor, double* d_out4, void* stream);
+#define FSQ_DTYPE_F64 0
+#define FSQ_DTYPE_U16 1
+int64_t fsq_phase_correlate_workspace_bytes(int n_pairs, int H, int W, int upsample_factor, int dtype, void* stream);
+int fsq_phase_correlate(const void* d_ref, const void* d_reg, int dtype, int n_pairs, int H, int W, int upsample_factor,
+                        double* d_out4, void* d_workspace, int64_t workspace_bytes, void* stream);
 
 /*
  * Spot photometry on the peak table: Spot.mexican_hat_photometry_metric, flexlibrary.py:172-210.

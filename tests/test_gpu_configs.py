@@ -164,10 +164,13 @@ def test_config5_fp16_pixel_loads(env):
             assert all(bits_equal(np.array([float(x) for x in a[k][:7]]), np.array([float(x) for x in b[k][:7]])).all() for k in a)
 
 
-def test_lane_pipeline_equals_single_engine(env):
+def test_lane_pipeline_equals_single_engine(env, monkeypatch):
     """engine.LanePipeline (two shares on their own streams / host threads, second one staggered) returns exactly what
-    one engine returns for the same fields."""
+    one engine returns for the same fields - with the thresholds lowered so that both lanes take the two-pass step
+    round and hand their late rounds to the high-priority stream (with raised wave priority) while the other lane runs."""
     torch, N, E, pflib, pc, synth, O = env
+    monkeypatch.setenv("FSQ_HIPRIO_BELOW", "1000")
+    monkeypatch.setenv("FSQ_TWO_PASS_MIN", "100")
     imgs = np.stack([synth.make_field(500 + i, (256, 256), 120) for i in range(12)])
     d_img = E.to_device_u16(imgs)
     prm = E.detect_params(5, pflib.default_correlation_matrix, 2)

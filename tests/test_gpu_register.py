@@ -50,3 +50,67 @@ def test_errors(pc):
         pc.phase_correlate(np.zeros((8, 8)), np.zeros((8, 9)))
     with pytest.raises(ValueError):
         pc.phase_correlate(np.zeros((2, 8, 8)), np.zeros((2, 8, 8)))
+
+
+def test_u16_input_equals_f64_and_full_spectrum_path(pc, monkeypatch):
+    """uint16 frames transformed as they sit in HBM give what the float64 copies give, bit for bit (the conversion is
+    exact); the older complex-to-complex path (FSQ_REGISTER_Z2Z=1) agrees on the shifts exactly and on error / diffphase to
+    rounding level."""
+    from fluorosequencingimageanalysis_amd import synth
+    frames, off = synth.make_cycle_stack(12, n_cycles=5, shape=(256, 256), n_spots=200)
+    odd = frames[:, :201, :77].copy()                   # odd sizes: vector-ALU DFT, Bluestein FFT lengths
+    for fr in (frames, odd):
+        for uf in (1, 20):
+            a = pc.phase_correlate_batch(fr[:-1], fr[1:], uf)
+            b = pc.phase_correlate_batch(fr[:-1].astype(np.float64), fr[1:].astype(np.float64), uf)
+            assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+            monkeypatch.setenv("FSQ_REGISTER_Z2Z", "1")
+            c = pc.phase_correlate_batch(fr[:-1].astype(np.float64), fr[1:].astype(np.float64), uf)
+            monkeypatch.delenv("FSQ_REGISTER_Z2Z")
+            assert np.array_equal(a[:, :2], c[:, :2])
+            assert np.abs(a[:, 2:] - c[:, 2:]).max() < 1e-9
+
+
+def test_two_threads_on_their_own_streams(pc):
+    """Same-shaped batches registered from two host threads on two streams at once (plans are cached per stream and
+    calls serialise on the plan lock while they enqueue): both get the single-threaded result."""
+    import threading
+    import torch
+    from fluorosequencingimageanalysis_amd import _native as N, engine as E, synth
+    frames, _ = synth.make_cycle_stack(13, n_cycles=9, shape=(128, 128), n_spots=60)
+    d = E.to_device_u16(frames)
+    ref = pc.Registrar(8, 128, 128, 20).register(d[:-1], d[1:]).cpu().numpy()
+    res, errs = {}, []
+
+    def work(k):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                R = pc.Registrar(8, 128, 128, 20)
+                for _ in range(20):
+                    out = R.register(d[:-1], d[1:])
+                st.synchronize()
+                res[k] = out.cpu().numpy()
+        except BaseException as e:      # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    assert np.array_equal(res[0], ref) and np.array_equal(res[1], ref)
+
+
+def test_unsupported_shape_fails_loudly(pc):
+    """A shape whose upsampled DFT fits neither the MFMA tiles nor the LDS twiddle vectors is refused
+    (NotImplementedError), not answered with garbage; many distinct batch sizes do not pile up plans."""
+    a = np.zeros((1, 2048, 2050), np.uint16)
+    a[0, 100, 100] = 1000
+    with pytest.raises(NotImplementedError):
+        pc.phase_correlate_batch(a, a, 20)
+    assert pc.phase_correlate_batch(a, a, 1)[0][:2].tolist() == [0.0, 0.0]
+    img = np.random.default_rng(0).integers(0, 4000, (40, 32, 48)).astype(np.uint16)
+    for n in range(1, 40, 3):                           # 13 batch sizes x 2 plans: beyond the cache bound
+        r = pc.phase_correlate_batch(img[:n], np.roll(img[:n], (2, -3), axis=(1, 2)), 1)
+        assert (r[:, 0] == -2).all() and (r[:, 1] == 3).all()
