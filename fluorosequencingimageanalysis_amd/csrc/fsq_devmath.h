@@ -328,7 +328,9 @@ FSQ_DEV int fsq_reduce_sincos(double x, double* a, double* da)
 }
 
 // sin and cos of the rotation angle (0 <= x < 105414350; the fit keeps theta in [0, 360] degrees)
-__device__ __noinline__ void fsq_sincos(double x, double* sn_out, double* cs_out)
+// (one out-of-line copy per kernel; the results come back in registers - pointer outputs would put them on the stack)
+struct FsqSinCos { double s, c; };
+__device__ __noinline__ FsqSinCos fsq_sincos_rv(double x)
 {
     unsigned k = (unsigned)(fsq_bits(x) >> 32) & 0x7fffffffu;
     double s, c;
@@ -351,6 +353,13 @@ __device__ __noinline__ void fsq_sincos(double x, double* sn_out, double* cs_out
         c = (m & 1) ? vc : vs;
         if (m & 2) c = -c;
     }
-    *sn_out = s;
-    *cs_out = c;
+    FsqSinCos r;
+    r.s = s; r.c = c;
+    return r;
+}
+__device__ __forceinline__ void fsq_sincos(double x, double* sn_out, double* cs_out)
+{
+    const FsqSinCos r = fsq_sincos_rv(x);
+    *sn_out = r.s;
+    *cs_out = r.c;
 }

@@ -654,13 +654,57 @@ static constexpr bool KB_LOOP = FSQ_KB_LOOP != 0;
 #ifndef FSQ_KB_WAVES
 #define FSQ_KB_WAVES 2
 #endif
+// The trial evaluation f(wa2) of the step round (mpfit.py:1245), residuals into the lane's LDS column.
+// FAST: the model's two divisions per pixel share their divisors (sigma_h, sigma_w, inside [0.75, 2] by the bounds) ->
+// fsq_div_by, and exp is the branch-free fsq_exp_bf; the operand ranges in which those equal `/` and exp() bit for bit
+// are checked on the way and the return value is true when one was left - the caller then repeats the evaluation with
+// FAST = false (plain divisions, full exp; same order of operations as fsq_model, gaussfitter.py:100-136).
+// Rows are a rolled loop (a fifth of the code), so the pixels come straight from the compact ROI copy and the residuals
+// go to LDS slots - no dynamically indexed register array, no scratch.
+FSQ_DEV int kb_res_slot(int i) { return i < 14 ? i : i + 7; }         // slots 14..20 hold the step vector wa1
+
+template <bool FAST>
+FSQ_DEV bool kb_trial_residual(const uint16_t* __restrict__ px, const double* p, double* myscr)
+{
+    bool bad = false;
+    int em = 0;
+    double s, c;
+    fsq_sincos(FSQ_PI_180 * p[6], &s, &c);
+    const double rcen_x = p[3] * c - p[2] * s;
+    const double rcen_y = p[3] * s + p[2] * c;
+    const FsqDivisor k4 = fsq_divisor(p[4]), k5 = fsq_divisor(p[5]);
+    if (FAST)       // |numerator| <= |p2| + |p3| + 8: bounded once the centre is
+        bad = !fsq_divisor_in_range(p[4]) || !fsq_divisor_in_range(p[5]) || !(__builtin_fabs(p[2]) <= 0x1p100) ||
+              !(__builtin_fabs(p[3]) <= 0x1p100);
+#pragma unroll 1
+    for (int xi = 0; xi < 5; xi++) {
+        const double x = (double)xi;
+#pragma unroll
+        for (int yi = 0; yi < 5; yi++) {
+            const double y = (double)yi;
+            const double xp = x * c - y * s;
+            const double yp = x * s + y * c;
+            const double nu = rcen_x - xp, nv = rcen_y - yp;
+            if (FAST) { em = min(em, fsq_expo(nu)); em = min(em, fsq_expo(nv)); }
+            const double u = fsq_div_sel<FAST>(nu, k4);
+            const double v = fsq_div_sel<FAST>(nv, k5);
+            const double e = -(u * u + v * v) / 2.;
+            const double g = p[0] + p[1] * (FAST ? fsq_exp_bf(e, &bad) : fsq_exp(e));
+            const int i = xi * 5 + yi;
+            myscr[kb_res_slot(i) * 64] = (double)px[i] - g;
+        }
+    }
+    if (FAST) bad = bad || (em < -FSQ_DIV_EN);
+    return bad;
+}
+
 template <bool ALIASED, bool RESUME>
 __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double* __restrict__ QB, const int* __restrict__ cntB_p,
                                                   double* __restrict__ QA_next, int* __restrict__ cntA_next,
                                                   double* __restrict__ QB_next, int* __restrict__ cntB_next,
                                                   double* __restrict__ QC, int* __restrict__ cntC, int lm_first)
 {
-    __shared__ double scr[21 * 64];
+    __shared__ double scr[32 * 64];
     if (c.wave_prio) __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x;
     const int cntB = *cntB_p;
@@ -797,12 +841,15 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
         // trial evaluation (mpfit.py:1245)
         double wa4[FSQ_NPIX];
         {
-            double g[FSQ_NPIX], data[FSQ_NPIX];
             asm volatile("" ::: "memory");          // the pixels are fetched here, not carried through lmpar
-            roi_compact(c, tag_slot(c, tag), data);
-            fsq_model(wa2, g);
+            const uint16_t* px = c.roi + (size_t)tag_slot(c, tag) * 32;
+            bool redo = kb_trial_residual<true>(px, wa2, myscr);
+            if (c.force_slow_mod > 0 && (tag_slot(c, tag) % c.force_slow_mod) == 0) redo = true;
+            if (__ballot(redo)) {                   // (never on image data: operands far outside the guarded ranges)
+                if (redo) kb_trial_residual<false>(px, wa2, myscr);
+            }
 #pragma unroll
-            for (int i = 0; i < FSQ_NPIX; i++) wa4[i] = data[i] - g[i];
+            for (int i = 0; i < FSQ_NPIX; i++) wa4[i] = myscr[kb_res_slot(i) * 64];
         }
         nfev++;
         fnorm1 = fsq_sqrt(dot25(wa4));

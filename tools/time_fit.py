@@ -21,7 +21,7 @@ import ctypes
 if hasattr(L,'fsq_debug_phase_cycles'):
     buf=(ctypes.c_ulonglong*16)(); L.fsq_debug_phase_cycles(buf,1); v=list(buf)
     names=['refill','J-evals','diff+peg','qrfac','pre-inner','lmpar','trial+logic','term']
-    tot=sum(v[:8])
+    tot=max(sum(v[:8]),1)
     for nm,c in zip(names,v[:8]): print('%-12s %6.2f%%'%(nm,100*c/tot))
     print('qlm load %.2f%%  gnorm+diag %.2f%%'%(100*v[10]/(tot+v[10]+v[11]),100*v[11]/(tot+v[10]+v[11])))
     print('inner passes per trip',v[8]/max(v[9],1),'trips',v[9])
