@@ -844,6 +844,11 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
             asm volatile("" ::: "memory");          // the pixels are fetched here, not carried through lmpar
             const uint16_t* px = c.roi + (size_t)tag_slot(c, tag) * 32;
             bool redo = kb_trial_residual<true>(px, wa2, myscr);
+#ifdef FSQ_EXPERIMENT_TRIAL_TWICE       // marginal cost of the trial evaluation: do it again (same results)
+            asm volatile("" ::: "memory");
+            redo = kb_trial_residual<true>(px, wa2, myscr) || redo;
+            asm volatile("" ::: "memory");
+#endif
             if (c.force_slow_mod > 0 && (tag_slot(c, tag) % c.force_slow_mod) == 0) redo = true;
             if (__ballot(redo)) {                   // (never on image data: operands far outside the guarded ranges)
                 if (redo) kb_trial_residual<false>(px, wa2, myscr);
@@ -1129,7 +1134,7 @@ enum { CTL_SLOW_TOTAL = 8, CTL_SLOW_CNT = 9, CTL_DONE = 16, CTL_INTS = CTL_DONE 
 
 struct RoundsCfg {
     int trips = 1, lm_first = FSQ_LMPAR_FIRST, sync_mask = 3, force_slow_mod = 0, force_redo = 0, no_wave_prio = 0, trace = 0;
-    int max_rounds = 0;
+    int max_rounds = 0, ka_lds_pad = 0, kb_lds_pad = 0;      // (debug: extra dynamic LDS per block = fewer waves per CU)
     long long two_pass_min = 524288, hiprio_below = 200000;
 };
 RoundsCfg read_cfg()
@@ -1146,6 +1151,8 @@ RoundsCfg read_cfg()
     if (getenv("FSQ_NO_WAVE_PRIO")) g.no_wave_prio = 1;
     if (getenv("FSQ_DEBUG_TRACE")) g.trace = 1;
     if ((e = getenv("FSQ_DEBUG_MAX_ROUNDS")) != nullptr) g.max_rounds = atoi(e);
+    if ((e = getenv("FSQ_DEBUG_KA_LDS_PAD")) != nullptr) g.ka_lds_pad = atoi(e);
+    if ((e = getenv("FSQ_DEBUG_KB_LDS_PAD")) != nullptr) g.kb_lds_pad = atoi(e);
     return g;
 }
 
@@ -1306,7 +1313,7 @@ struct FsqFitQueue {
             else if (gA > full) gA = full;
         }
         if (gA > 0)         // (also zeroes the counters of set nxt)
-            hipLaunchKernelGGL(kA_jacobian<true>, dim3((unsigned)gA), dim3(64), 0, s, c, QA[cur], cA[cur], QB[cur], cB[cur], SQ, cSlow, cA[nxt]);
+            hipLaunchKernelGGL(kA_jacobian<true>, dim3((unsigned)gA), dim3(64), cfg.ka_lds_pad, s, c, QA[cur], cA[cur], QB[cur], cB[cur], SQ, cSlow, cA[nxt]);
         else
             FSQ_HIP_CHECK(hipMemsetAsync(cA[nxt], 0, 4 * sizeof(int), s));
         if (slow_pending > 0) {
@@ -1331,8 +1338,8 @@ struct FsqFitQueue {
             const bool two_pass = nB > cfg.two_pass_min && cfg.lm_first < 10;
             const int lm_first = two_pass ? cfg.lm_first : 10;
             if (ref) {
-                hipLaunchKernelGGL((kB_step<true, false>), dim3((unsigned)gB), dim3(64), 0, s, c, QB[cur], cB[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur], lm_first);
-                if (two_pass) hipLaunchKernelGGL((kB_step<true, true>), dim3((unsigned)gB), dim3(64), 0, s, c, QC, cC[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur], 10);
+                hipLaunchKernelGGL((kB_step<true, false>), dim3((unsigned)gB), dim3(64), cfg.kb_lds_pad, s, c, QB[cur], cB[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur], lm_first);
+                if (two_pass) hipLaunchKernelGGL((kB_step<true, true>), dim3((unsigned)gB), dim3(64), cfg.kb_lds_pad, s, c, QC, cC[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur], 10);
             } else {
                 hipLaunchKernelGGL((kB_step<false, false>), dim3((unsigned)gB), dim3(64), 0, s, c, QB[cur], cB[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur], lm_first);
                 if (two_pass) hipLaunchKernelGGL((kB_step<false, true>), dim3((unsigned)gB), dim3(64), 0, s, c, QC, cC[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur], 10);
