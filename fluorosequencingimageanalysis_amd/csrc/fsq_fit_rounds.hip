@@ -244,6 +244,9 @@ FSQ_DEV KaBody ka_fetch_body(const Ctx& c, const double* qa, long long cap, int 
 // The FAST build also zeroes the queue counters of the next round (nobody reads or appends to them during kA).
 // With one trip per block (the default grid) there is no next trip to prefetch for; FSQ_KA_PIPELINE=1 compiles the
 // software pipeline back in for resident grids (FSQ_TRIPS_PER_BLOCK=0).
+#ifndef FSQ_KA_LANES_DEFAULT
+#define FSQ_KA_LANES_DEFAULT 4
+#endif
 #ifndef FSQ_KA_PIPELINE
 #define FSQ_KA_PIPELINE 0
 #endif
@@ -637,6 +640,8 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
     }
     RPH_FLUSH(8)
 }
+
+#include "fsq_fit_rounds_ka8.h"
 
 // ---------------------------------------------------------------------------------------------------
 // kB: step round.  One lane per fit, grid-stride over list B.
@@ -1134,6 +1139,7 @@ enum { CTL_SLOW_TOTAL = 8, CTL_SLOW_CNT = 9, CTL_DONE = 16, CTL_INTS = CTL_DONE 
 
 struct RoundsCfg {
     int trips = 1, lm_first = FSQ_LMPAR_FIRST, sync_mask = 3, force_slow_mod = 0, force_redo = 0, no_wave_prio = 0, trace = 0;
+    int ka_lanes = FSQ_KA_LANES_DEFAULT;               // lanes per fit in the Jacobian round: 8 (kA8_jacobian) or 4 (kA_jacobian)
     int max_rounds = 0, ka_lds_pad = 0, kb_lds_pad = 0;      // (debug: extra dynamic LDS per block = fewer waves per CU)
     long long two_pass_min = 524288, hiprio_below = 200000;
 };
@@ -1151,6 +1157,7 @@ RoundsCfg read_cfg()
     if (getenv("FSQ_NO_WAVE_PRIO")) g.no_wave_prio = 1;
     if (getenv("FSQ_DEBUG_TRACE")) g.trace = 1;
     if ((e = getenv("FSQ_DEBUG_MAX_ROUNDS")) != nullptr) g.max_rounds = atoi(e);
+    if ((e = getenv("FSQ_KA_LANES")) != nullptr && (atoi(e) == 4 || atoi(e) == 8)) g.ka_lanes = atoi(e);
     if ((e = getenv("FSQ_DEBUG_KA_LDS_PAD")) != nullptr) g.ka_lds_pad = atoi(e);
     if ((e = getenv("FSQ_DEBUG_KB_LDS_PAD")) != nullptr) g.kb_lds_pad = atoi(e);
     return g;
@@ -1312,15 +1319,20 @@ struct FsqFitQueue {
             if (cfg.trips > 0) gA = (gA + cfg.trips - 1) / cfg.trips;
             else if (gA > full) gA = full;
         }
-        if (gA > 0)         // (also zeroes the counters of set nxt)
+        if (gA > 0 && cfg.ka_lanes == 8)         // (kA also zeroes the counters of set nxt)
+            hipLaunchKernelGGL(kA8_jacobian<true>, dim3((unsigned)((boundA + 7) / 8)), dim3(64), cfg.ka_lds_pad, s, c, QA[cur], cA[cur], QB[cur], cB[cur], SQ, cSlow, cA[nxt]);
+        else if (gA > 0)
             hipLaunchKernelGGL(kA_jacobian<true>, dim3((unsigned)gA), dim3(64), cfg.ka_lds_pad, s, c, QA[cur], cA[cur], QB[cur], cB[cur], SQ, cSlow, cA[nxt]);
         else
             FSQ_HIP_CHECK(hipMemsetAsync(cA[nxt], 0, 4 * sizeof(int), s));
         if (slow_pending > 0) {
             // fits that left the guarded operand ranges since the host last looked: the plain-division build takes them
             // from the slow queue and appends their queue-B records to this round's
-            long long gS = (alive + 15) / 16;       // the slow queue may have grown since the host looked: size for all
-            hipLaunchKernelGGL(kA_jacobian<false>, dim3((unsigned)gS), dim3(64), 0, s, c, SQ, cSlow, QB[cur], cB[cur], SQ, cSlow, cA[nxt]);
+            // (the slow queue may have grown since the host looked: size for all)
+            if (cfg.ka_lanes == 8)
+                hipLaunchKernelGGL(kA8_jacobian<false>, dim3((unsigned)((alive + 7) / 8)), dim3(64), 0, s, c, SQ, cSlow, QB[cur], cB[cur], SQ, cSlow, cA[nxt]);
+            else
+                hipLaunchKernelGGL(kA_jacobian<false>, dim3((unsigned)((alive + 15) / 16)), dim3(64), 0, s, c, SQ, cSlow, QB[cur], cB[cur], SQ, cSlow, cA[nxt]);
             FSQ_HIP_CHECK(hipMemsetAsync(cSlow, 0, sizeof(int), s));
             nB += slow_pending;
             if (alive < nB) alive = nB;

@@ -106,6 +106,26 @@ def test_textbook_mode_equals_patched_reference(env, name):
     _rows_equal_golden(gpu_fit_rois(torch, N, rois_of(img, g["candidates"]), mode=1), g)
 
 
+def test_eight_lane_jacobian_round(env, monkeypatch):
+    """FSQ_KA_LANES=8 selects kA8_jacobian (one column per lane, 8 fits per wave, 4 waves per SIMD - an A/B variant of the
+    Jacobian round, measured 5 % slower than the 4-lane one): same bits, incl. the plain-division build
+    and the norm re-computation branch."""
+    torch, N, O = env
+    g, img = load_field("f3_hard_256")
+    rois = rois_of(img, g["candidates"])
+    monkeypatch.setenv("FSQ_KA_LANES", "8")
+    _rows_equal_golden(gpu_fit_rois(torch, N, rois), g)
+    monkeypatch.setenv("FSQ_DEBUG_FORCE_SLOW", "3")
+    _rows_equal_golden(gpu_fit_rois(torch, N, rois), g)
+    assert N.lib().fsq_fit_last_slow_count() > 0
+    monkeypatch.delenv("FSQ_DEBUG_FORCE_SLOW")
+    monkeypatch.setenv("FSQ_DEBUG_FORCE_NORM_RECOMPUTE", "1")
+    a = gpu_fit_rois(torch, N, rois)
+    monkeypatch.setenv("FSQ_KA_LANES", "4")
+    b = gpu_fit_rois(torch, N, rois)
+    assert a.tobytes() == b.tobytes()
+
+
 def test_textbook_mode(env):
     torch, N, O = env
     g, img = load_field("f5_small_96")
