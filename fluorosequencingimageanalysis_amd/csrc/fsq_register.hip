@@ -323,11 +323,14 @@ __global__ void k6_coarse(const Peak* __restrict__ part, int parts, int n_pairs,
                           const double* __restrict__ psums /*[pairs][nsum][2]*/, int nsum, double* __restrict__ sums /*[pairs][2]*/,
                           double* __restrict__ shifts /*[pairs][2]*/, double* __restrict__ offs /*[pairs][2]*/, double* __restrict__ out4)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_pairs) return;
+    // one 64-lane block per pair: the partial sums are added up in a fixed order (strided per lane, then a shuffle tree)
+    const int p = blockIdx.x;
     {
         double sf = 0.0, sg = 0.0;
-        for (int k = 0; k < nsum; k++) { sf += psums[((size_t)p * nsum + k) * 2]; sg += psums[((size_t)p * nsum + k) * 2 + 1]; }
+        for (int k = threadIdx.x; k < nsum; k += 64) { sf += psums[((size_t)p * nsum + k) * 2]; sg += psums[((size_t)p * nsum + k) * 2 + 1]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { sf += __shfl_xor(sf, o); sg += __shfl_xor(sg, o); }
+        if (threadIdx.x != 0) return;
         sums[2 * p] = sf; sums[2 * p + 1] = sg;
     }
     Peak best = part[(size_t)p * parts];
@@ -589,7 +592,7 @@ extern "C" int fsq_phase_correlate(const void* d_ref, const void* d_reg, int dty
         hipLaunchKernelGGL(k6_cross_power_half, dim3(gx, n_pairs), dim3(256), 0, s, Fh, Gh, Ph, H, W, Wh, psums);
         if (hipfftExecZ2D(inv.h, (hipfftDoubleComplex*)Ph, (hipfftDoubleReal*)cc) != HIPFFT_SUCCESS) return FSQ_EHIP;
         hipLaunchKernelGGL(k6_argmax_real_part, dim3(L.parts, n_pairs), dim3(256), 0, s, cc, npix, L.parts, part);
-        hipLaunchKernelGGL(k6_coarse, dim3(pb), dim3(64), 0, s, part, L.parts, n_pairs, H, W, uf, psums, (int)gx, sums, shifts, offs, d_out4);
+        hipLaunchKernelGGL(k6_coarse, dim3(n_pairs), dim3(64), 0, s, part, L.parts, n_pairs, H, W, uf, psums, (int)gx, sums, shifts, offs, d_out4);
         if (uf > 1) {
             cplx* T = (cplx*)(ws + L.T);
             if (use_mfma) {
@@ -620,7 +623,7 @@ extern "C" int fsq_phase_correlate(const void* d_ref, const void* d_reg, int dty
         if (hipfftExecZ2Z(fwd.h, (hipfftDoubleComplex*)P, (hipfftDoubleComplex*)P, HIPFFT_BACKWARD) != HIPFFT_SUCCESS) return FSQ_EHIP;
         hipLaunchKernelGGL(k6_argmax, dim3(n_pairs), dim3(256), 0, s, P, npix, 1.0, 0, part);     // parts = 1 layout below
         // (k6_coarse reads `parts` entries per pair: hand it the single complex peak with parts = 1; imaginary part kept)
-        hipLaunchKernelGGL(k6_coarse, dim3(pb), dim3(64), 0, s, part, 1, n_pairs, H, W, uf, psums, (int)gx, sums, shifts, offs, d_out4);
+        hipLaunchKernelGGL(k6_coarse, dim3(n_pairs), dim3(64), 0, s, part, 1, n_pairs, H, W, uf, psums, (int)gx, sums, shifts, offs, d_out4);
         if (uf > 1) {
             hipLaunchKernelGGL(k6_cross_power2, dim3(blocks), dim3(256), 0, s, F, G, P, ntot);
             if (use_mfma) {
