@@ -3,7 +3,7 @@
 //
 // kA_jacobian gives a fit 4 lanes, each holding two of the 8 columns (7 Jacobian columns + the residual vector): 250
 // VGPRs and 19.8 KB of LDS per wave, i.e. 2 waves per SIMD - and the round is latency-bound (PMC: a wave has a VALU
-// instruction in flight 36 % of its resident cycles; halving the occupancy costs 1.7x, tools/r02_exp2.sh).  Here lane c
+// instruction in flight 36 % of its resident cycles; halving the occupancy costs 1.7x, tools/occupancy_sensitivity.sh).  Here lane c
 // of an OCT owns column c alone (slot 7 = f(x), which becomes Q^T f): 8 fits per wave, about half the registers and
 // half the LDS, 4 waves per SIMD.  Per fit that is ~10 % more wave-instructions (the pivot bookkeeping and the pivot
 // column's scaling are per wave, not per column) against twice the waves to hide the LDS and dependency latencies behind.

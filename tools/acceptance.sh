@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-2 acceptance run: whole GPU suite, smoke(), the driver's bench command, then the profile collection
 cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r02_final; mkdir -p $O
+O=gpurun_out/acceptance; mkdir -p $O
 timeout -k 10 1100 python3 -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; echo "gpu tests rc=$?"; tail -4 $O/pytest_gpu.log
 timeout -k 10 300 python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
 timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err || { tail -5 $O/bench.err; exit 1; }
