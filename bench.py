@@ -74,6 +74,9 @@ def main():
                     help="stream: continuous batching of the LM fits across steps (engine.StreamPipeline); "
                          "lanes: every step a stand-alone batch, worked as --lanes shares (engine.LanePipeline)")
     ap.add_argument("--lanes", type=int, default=2, help="lanes pipeline: shares of the batch worked side by side")
+    ap.add_argument("--queues", type=int, default=2,
+                    help="stream pipeline: fit queues (each with its own streams and host thread) the fields of every step are "
+                         "split over; the kernels of different queues overlap each other's ramp-down")
     ap.add_argument("--depth", type=int, default=16, help="stream pipeline: batches in flight at most")
     ap.add_argument("--inject-below", type=int, default=None, help="stream pipeline: submit the next batch once fewer fits are alive")
     ap.add_argument("--config", type=int, default=2, choices=(2, 3),
@@ -240,46 +243,79 @@ def _barrier(torch, dist, world):
 
 
 def run_stream(a, torch, dist, D, E, N, d_img, imgs, prm, dev, rank, world):
-    """K steps = K batches streamed through engine.StreamPipeline (continuous batching of the LM fits): a step's
+    """K steps = K batches streamed through engine.StreamPipelineGroup: continuous batching of the LM fits (a step's
     detection, its fits and its consolidation all happen inside the timed region, but the slow fits of one step finish
-    inside the round launches of the following steps instead of in hundreds of nearly empty launches of their own."""
-    pipe = E.StreamPipeline(a.fields, a.size, a.size, depth=a.depth, inject_below=a.inject_below, device=dev)
-    sharded = D.ShardedTables(dev) if world > 1 else None
-    kept = [0]
+    inside the round launches of the following steps instead of in hundreds of nearly empty launches of their own), the
+    fields of every step split over `--queues` fit queues on their own streams so that their kernels overlap each other's
+    ramp-down.  With N > 1 every step's kept tables go to rank 0 (the one exchange of the path), issued by the main thread
+    in (step, queue) order while the queues' threads keep working."""
+    import queue as _queue
+    import threading
+    group = E.StreamPipelineGroup(a.fields, a.size, a.size, queues=a.queues, depth=a.depth, inject_below=a.inject_below, device=dev)
+    Q = len(group.pipes)
+    kept = [0] * Q
+    box = _queue.Queue()
 
-    def on_done(j, eng, total):
-        if sharded is not None:         # the one exchange of the path: this step's peak table to rank 0, in step order
-            sharded.push(j, eng, total)
-        kept[0] = eng.nkeep[eng.n_fields]       # (device scalar; read after the run)
+    def on_done(j, k, eng, total):
+        kept[k] = eng.nkeep[eng.n_fields]           # (device scalar; read after the run)
+        if world > 1:
+            table = eng.kept_table()[0]
+            ev = torch.cuda.Event()
+            ev.record()
+            box.put((j, k, table, ev))
 
     def steps(n):
-        totals = pipe.run([(d_img, prm)] * n, on_done)
-        if sharded is not None:
-            sharded.flush()
-        return totals
+        res, errs = [None], []
+
+        def body():
+            try:
+                res[0] = group.run([(d_img, prm)] * n, on_done)
+            except BaseException as e:      # noqa: BLE001
+                errs.append(e)
+                box.put(None)
+        if world == 1:
+            return group.run([(d_img, prm)] * n, on_done)
+        th = threading.Thread(target=body, daemon=True)
+        th.start()
+        ready = {}
+        for j in range(n):
+            for k in range(Q):
+                while (j, k) not in ready:
+                    item = box.get()
+                    if item is None:
+                        raise errs[0]
+                    ready[(item[0], item[1])] = item[2:]
+                table, ev = ready.pop((j, k))
+                torch.cuda.current_stream().wait_event(ev)
+                D.gather_tables(table, 0)
+        th.join()
+        if errs:
+            raise errs[0]
+        return res[0]
 
     steps(1)                            # page everything in
     steps(a.warmup)
     _barrier(torch, dist, world)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    r0 = pipe.queue.rounds
-    ev0.record(pipe.queue.stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(Q)]
+    r0 = [p.queue.rounds for p in group.pipes]
+    for k in range(Q):
+        ev[k][0].record(group.pipes[k].queue.stream)
     t0 = time.perf_counter()
     totals = steps(a.steps)
-    ev1.record(pipe.queue.stream)
+    for k in range(Q):
+        ev[k][1].record(group.pipes[k].queue.stream)
     _barrier(torch, dist, world)
     dt = time.perf_counter() - t0
-    busy_ms = ev0.elapsed_time(ev1)
-    rounds = pipe.queue.rounds - r0
-    how = ("the steps are streamed through one fit queue (continuous batching, at most %d batches in flight, next batch "
-           "submitted below %d live fits; %d rounds for %d steps)" % (pipe.depth, pipe.inject_below, rounds, a.steps))
-    eng0 = pipe.engines[0]
+    busy_ms = max(ev[k][0].elapsed_time(ev[k][1]) for k in range(Q))        # the queues' streams are busy side by side
+    rounds = [group.pipes[k].queue.rounds - r0[k] for k in range(Q)]
+    how = ("the steps are streamed through %d fit queue(s) on their own streams, the fields of a step split between them "
+           "(continuous batching: at most %d batches in flight per queue, next batch submitted below %d live fits; %s rounds "
+           "for %d steps)" % (Q, group.pipes[0].depth, group.pipes[0].inject_below, rounds, a.steps))
 
     def cand_tables():
-        with torch.cuda.stream(pipe.side):
-            t = eng0.detect(d_img, prm)
-            return eng0.candidates(t)
-    return dt, totals[0], int(kept[0]), busy_ms, {"rounds": int(rounds), "steps": a.steps}, how, cand_tables
+        e = E.Engine(a.fields, a.size, a.size, device=dev, fit_workspace=False)
+        return e.candidates(e.detect(d_img, prm))
+    return dt, totals[0], sum(int(x) for x in kept), busy_ms, {"rounds": rounds, "steps": a.steps, "queues": Q}, how, cand_tables
 
 
 def run_lanes(a, torch, dist, D, E, N, d_img, prm, dev, rank, world):

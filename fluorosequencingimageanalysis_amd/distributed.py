@@ -88,25 +88,6 @@ def gather_tables(local_rows, dst=0):
     return None, counts
 
 
-class ShardedTables:
-    """Rank-side half of the peak-table exchange for a STREAM of batches (engine.StreamPipeline.run's on_done):
-    every batch's kept table goes to `dst` with gather_tables, in batch order on every rank, whatever order the
-    batches finished in locally (the gather is a collective: all ranks must issue it for the same batch)."""
-
-    def __init__(self, device, dst=0, keep_last=True):
-        self.dst, self.next, self.ready = dst, 0, {}
-        self.last = None            # (table, counts) of the most recent gather on dst
-
-    def push(self, j, eng, total):
-        self.ready[j] = eng.kept_table()[0]
-        self.flush()
-
-    def flush(self):
-        while self.next in self.ready:
-            self.last = gather_tables(self.ready.pop(self.next), self.dst)
-            self.next += 1
-
-
 def _partition(weights_or_n, world, partition):
     if partition == "round_robin":
         return [shard_fields(weights_or_n, r, world) for r in range(world)]

@@ -449,6 +449,53 @@ class StreamPipeline:
         self.queue.close()
 
 
+class StreamPipelineGroup:
+    """Several StreamPipelines side by side: the fields of every batch are split into contiguous shares, share k is
+    worked by pipeline k (its own fit queue, its own pair of HIP streams, its own host thread).  A round of the LM fit is
+    two or three kernels whose last waves run alone while the launch drains; with a second queue on other streams the
+    hardware fills that ramp-down with the other queue's kernels (+3.4 % fits/s with two queues on bench.py's batches,
+    nothing more with three).  Results per field are those of Engine.run."""
+
+    def __init__(self, n_fields, H, W, queues=2, device=None, **kw):
+        torch = _torch()
+        self.torch = torch
+        self.dev = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
+        q = max(1, min(int(queues), int(n_fields)))
+        self.cut = [int(n_fields) * k // q for k in range(q + 1)]
+        self.pipes = [StreamPipeline(self.cut[k + 1] - self.cut[k], H, W, device=self.dev, **kw) for k in range(q)]
+
+    def run(self, jobs, on_done=None, **kw):
+        """jobs: list of (d_img[n_fields, H, W], detect_params).  on_done(job_index, queue_index, engine, total) is called
+        in queue k's thread with that pipeline's side stream current (see StreamPipeline.run); the engine holds the fields
+        cut[k] .. cut[k+1] of the job.  Returns the candidate totals per job (summed over the shares)."""
+        import threading
+        jobs = list(jobs)
+        totals = [None] * len(self.pipes)
+        errs = []
+
+        def body(k):
+            try:
+                self.torch.cuda.set_device(self.dev)
+                lo, hi = self.cut[k], self.cut[k + 1]
+                cb = None if on_done is None else (lambda j, eng, total: on_done(j, k, eng, total))
+                totals[k] = self.pipes[k].run([(d[lo:hi], prm) for d, prm in jobs], cb, **kw)
+            except BaseException as e:      # noqa: BLE001 - handed to the caller below
+                errs.append(e)
+
+        ths = [threading.Thread(target=body, args=(k,), daemon=True) for k in range(len(self.pipes))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errs:
+            raise errs[0]
+        return [sum(t[j] for t in totals) for j in range(len(jobs))]
+
+    def close(self):
+        for p in self.pipes:
+            p.close()
+
+
 def fit_rois(rois, mode=N.MODE_REF):
     """LM-fit stand-alone 5x5 ROIs (uint16[n,5,5]); returns the FsqRow table on the host."""
     torch = _torch()

@@ -72,6 +72,48 @@ def test_stream_pipeline_equals_single_engine(env, inject_below, depth):
     pipe.close()
 
 
+def test_pipeline_group_equals_single_engine(env):
+    """engine.StreamPipelineGroup: the fields of every batch split over two fit queues on their own streams / threads -
+    every share equals the corresponding fields of the stand-alone run."""
+    torch, N, E, pflib, synth = env
+    n, H, W = 6, 128, 128
+    prm = E.detect_params(5, pflib.default_correlation_matrix, 2)
+    batches = [np.stack([synth.make_field(700 + 10 * b + i, (H, W), 15 + 9 * b) for i in range(n)]) for b in range(4)]
+    d_imgs = [E.to_device_u16(x) for x in batches]
+    group = E.StreamPipelineGroup(n, H, W, queues=2, depth=3, inject_below=1500)
+    assert group.cut == [0, 3, 6]
+    got = {}
+
+    def on_done(j, k, eng, total):
+        got[(j, k)] = (eng.all_rows(total), eng.counts.cpu().numpy().copy(), eng.kept_table()[0].cpu().numpy().copy())
+
+    totals = group.run([(d, prm) for d in d_imgs], on_done)
+    group.close()
+    for j, d in enumerate(d_imgs):
+        one = E.Engine(n, H, W)
+        total = one.run(d, prm)
+        assert totals[j] == total
+        rows = one.all_rows(total)
+        counts = one.counts.cpu().numpy()
+        table = one.kept_table()[0].cpu().numpy().view(N.ROW_DTYPE).reshape(-1)
+        lo = 0
+        klo = 0
+        for k in range(2):
+            r, c, t = got[(j, k)]
+            nk = int(c[:3].sum())
+            a, b = r.copy(), rows[lo:lo + nk].copy()
+            for x in (a, b):
+                x["key_h"] = x["key_w"] = -1
+            a["field"] += 3 * k                         # rows carry the field index inside their share
+            assert a.tobytes() == b.tobytes()
+            t = t.view(N.ROW_DTYPE).reshape(-1).copy()
+            t["field"] += 3 * k
+            assert t.tobytes() == table[klo:klo + len(t)].tobytes()
+            lo += nk
+            klo += len(t)
+        assert lo == total and klo == len(table)
+
+
 def test_stream_pipeline_golden_field(env):
     """The reference's own table for golden field f1 comes out of the pipeline while other batches share its rounds."""
     torch, N, E, pflib, synth = env
