@@ -102,3 +102,32 @@ def test_centroid_goldens_cover_the_cases():
     assert not np.array_equal(a, b)                     # the s_n cut-off branch (same coordinates as the prior spot) is taken
     with pytest.raises(ValueError):                     # all-zero search window: centre of mass is NaN
         O.centroid_tracking(np.zeros((2, 16, 16), np.uint16), [(8, 8)])
+
+
+def test_flexlibrary_host_helpers_match_reference_goldens():
+    """The host-side helpers of the flexlibrary mirror (accumulate_offsets, discard_dropouts, round_coordinates,
+    offset arithmetic: flexlibrary.py:567-678) against the recorded reference runs: the number of spots
+    discard_dropouts drops per case equals the reference's, and the cumulative offsets are Python's left-to-right sums."""
+    from fluorosequencingimageanalysis_amd import flexlibrary as fl
+
+    class S(object):
+        def __init__(self, h, w):
+            self.h, self.w = int(h), int(w)
+    for name, frame_hw, offsets, shape, radius, spot_radius, traces, discarded in load_cases():
+        cum = fl.Experiment.accumulate_offsets(offsets)
+        assert cum[0] == (0, 0) and len(cum) == len(offsets)
+        for f in range(len(offsets)):
+            assert cum[f] == (sum([o[0] for o in offsets[:f + 1]]), sum([o[1] for o in offsets[:f + 1]]))
+            assert fl.Experiment.get_cumulative_offset(offsets, f) == cum[f]
+        dropped = 0
+        for f, hw in enumerate(frame_hw):
+            spots = [S(h, w) for h, w in hw]
+            kept, nd = fl.Experiment.discard_dropouts(spots, [cum[f]] * len(spots), cum, shape, spot_radius)
+            assert len(kept) + nd == len(spots)
+            dropped += nd
+        assert dropped == discarded, name
+    assert fl.Experiment.round_coordinates(2.5, -2.5) == (3, -3)                   # Python-2 round
+    assert fl.Experiment.unapply_offset(fl.Experiment.apply_offset((3, 4), (1.5, -2)), (1.5, -2)) == (3.0, 4)
+    assert fl.Experiment.offset_frame_coordinates([(0, 0), (1, 2), (3, 4)], (10, 10), 2, 1) == (13, 14)
+    with pytest.raises(ValueError):
+        fl.Experiment.accumulate_offsets([(1, 0)])

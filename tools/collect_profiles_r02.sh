@@ -5,13 +5,15 @@ set -e
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 R=${1:-r02}
-mkdir -p gpurun_out/$R
+rm -rf gpurun_out/$R; mkdir -p gpurun_out/$R
 B="python3 bench.py --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats -- $B --steps 6 --warmup 1 > gpurun_out/$R/bench_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats_q1 -- $B --steps 6 --warmup 1 --queues 1 > gpurun_out/$R/bench_stats_q1.log 2>&1
 echo "stats done"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats_cfg3 -- $B --config 3 --steps 10 --warmup 2 > gpurun_out/$R/bench_stats_cfg3.log 2>&1
 echo "cfg3 stats done"
-S="--steps 2 --warmup 0 --fields 256"
+# counters with ONE fit queue: kernels of a single stream do not overlap, so per-kernel durations add up to busy time
+S="--steps 2 --warmup 0 --fields 256 --queues 1"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/$R/pmc_fetch -- $B $S > gpurun_out/$R/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/$R/pmc_write -- $B $S > gpurun_out/$R/bench_write.log 2>&1
 echo "traffic done"

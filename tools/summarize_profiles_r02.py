@@ -21,9 +21,12 @@ def kind(name):
     return "other"
 
 
-for tag, title, steps in (("stats", "python3 bench.py --steps 6 --warmup 1 (stream pipeline, 1 + 1 + 6 = 8 steps run)", 8),
+for tag, title, steps in (("stats", "python3 bench.py --steps 6 --warmup 1 (the default: two fit queues side by side; 1 + 1 + 6 = 8 steps run). "
+                           "Kernels of the two queues run CONCURRENTLY: their durations overlap and add up to more than wall time", 8),
+                          ("stats_q1", "python3 bench.py --steps 6 --warmup 1 --queues 1 (one fit queue: kernels run one after the other, "
+                           "durations add up to busy time)", 8),
                           ("stats_cfg3", "python3 bench.py --config 3 --steps 10 --warmup 2 (1 + 2 + 10 = 13 registration calls)", 13)):
-    f = glob.glob(base + "/%s/*/*kernel_stats.csv" % tag)
+    f = sorted(glob.glob(base + "/%s/*/*kernel_stats.csv" % tag))
     if not f:
         continue
     rows = list(csv.DictReader(open(f[0])))
@@ -35,11 +38,11 @@ for tag, title, steps in (("stats", "python3 bench.py --steps 6 --warmup 1 (stre
                    "ms_per_step": tot / steps, "pct": float(r["Percentage"])})
         md.append("| `%s` | %s | %.2f | %.1f | %.2f | %s |" % (r["Name"][:90], r["Calls"], tot, float(r["AverageNs"]) / 1e3, tot / steps, r["Percentage"]))
     out["kernel_stats_" + tag] = ks
-    if tag == "stats":
+    if tag in ("stats", "stats_q1"):
         fit = sum(float(r["TotalDurationNs"]) for r in rows if kind(r["Name"]) in ("kA_jacobian", "kB_step", "kinit", "kfinish")) / 1e6
         allk = sum(float(r["TotalDurationNs"]) for r in rows) / 1e6
-        out["fit_kernels_ms_per_step"] = fit / steps
-        out["all_kernels_ms_per_step"] = allk / steps
+        out["fit_kernels_ms_per_step_" + tag] = fit / steps
+        out["all_kernels_ms_per_step_" + tag] = allk / steps
         md += ["", "LM fit (kinit + every kA_jacobian / kB_step round + kfinish): %.1f ms of kernel time per step; all kernels %.1f ms per step "
                "(detection and consolidation run on a second stream, concurrently with the rounds)." % (fit / steps, allk / steps), ""]
     else:
