@@ -330,7 +330,15 @@ FSQ_DEV int fsq_reduce_sincos(double x, double* a, double* da)
 // sin and cos of the rotation angle (0 <= x < 105414350; the fit keeps theta in [0, 360] degrees)
 // (one out-of-line copy per kernel; the results come back in registers - pointer outputs would put them on the stack)
 struct FsqSinCos { double s, c; };
-__device__ __noinline__ FsqSinCos fsq_sincos_rv(double x)
+#ifndef FSQ_SINCOS_INLINE
+#define FSQ_SINCOS_INLINE 0
+#endif
+#if FSQ_SINCOS_INLINE
+__device__ __forceinline__
+#else
+__device__ __noinline__
+#endif
+FsqSinCos fsq_sincos_rv(double x)
 {
     unsigned k = (unsigned)(fsq_bits(x) >> 32) & 0x7fffffffu;
     double s, c;

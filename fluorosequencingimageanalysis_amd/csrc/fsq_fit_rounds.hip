@@ -703,6 +703,8 @@ FSQ_DEV bool kb_trial_residual(const uint16_t* __restrict__ px, const double* p,
     return bad;
 }
 
+FSQ_DEV double kb_late_load(const double* p) { asm volatile("" ::: "memory"); return *p; }
+
 template <bool ALIASED, bool RESUME>
 __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double* __restrict__ QB, const int* __restrict__ cntB_p,
                                                   double* __restrict__ QA_next, int* __restrict__ cntA_next,
@@ -737,7 +739,10 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
             q.qtf[k] = qb[(B_QTF + k) * cap]; q.dg[k] = qb[(A_DIAG + k) * cap]; q.sdiag[k] = qb[(B_SDIAG + k) * cap];
             xq[k] = qb[(A_X + k) * cap];
         }
-        const double llim1 = qb[A_LLIM1 * cap], gnorm = qb[B_GNORM * cap];
+        const double llim1 = qb[A_LLIM1 * cap];
+        // (gnorm is only copied through and tested once at the end: it is read where it is needed instead of being
+        // carried through lmpar - the kernel is at its register limit)
+#define KB_GNORM() kb_late_load(qb + B_GNORM * cap)
         double fnorm = qb[A_FNORM * cap], par = qb[A_PAR * cap], delta = qb[A_DELTA * cap], xnorm = qb[A_XNORM * cap], fnorm1;
 #pragma unroll
         for (int k = 0; k < FSQ_NP; k++) myscr[k * 64] = q.dg[k];
@@ -771,7 +776,7 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
                     }
                     qn[A_LLIM1 * cap] = llim1; qn[A_FNORM * cap] = fnorm; qn[A_PAR * cap] = par; qn[A_DELTA * cap] = delta;
                     qn[A_XNORM * cap] = xnorm; qn[A_ITER * cap] = pack2(niter, nfev);
-                    qn[B_GNORM * cap] = gnorm; qn[B_IPVT * cap] = pack2((int)ipvt, 0);
+                    qn[B_GNORM * cap] = KB_GNORM(); qn[B_IPVT * cap] = pack2((int)ipvt, 0);
 #pragma unroll
                     for (int i = 0; i < FSQ_NP; i++)
 #pragma unroll
@@ -921,7 +926,7 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
             if (niter >= 200) status = 5;
             if ((__builtin_fabs(actred) <= FSQ_MACHEP) && (prered <= FSQ_MACHEP) && (0.5 * ratio <= 1)) status = 6;
             if (delta <= FSQ_MACHEP * xnorm) status = 7;
-            if (gnorm <= FSQ_MACHEP) status = 8;
+            if (KB_GNORM() <= FSQ_MACHEP) status = 8;
         }
         if (status == 0 && !accepted) {
             bool fin = __builtin_isfinite(ratio);
@@ -952,9 +957,10 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
                 qn[A_LLIM1 * cap] = llim1; qn[A_FNORM * cap] = fnorm; qn[A_PAR * cap] = par; qn[A_DELTA * cap] = delta;
                 qn[A_XNORM * cap] = xnorm; qn[A_ITER * cap] = pack2(niter, nfev);
                 if (toB) {
-                    qn[B_GNORM * cap] = gnorm; qn[B_IPVT * cap] = pack2((int)ipvt, 0);
+                    qn[B_GNORM * cap] = KB_GNORM(); qn[B_IPVT * cap] = pack2((int)ipvt, 0);
 #pragma unroll
                     for (int k = 0; k < FSQ_NP; k++) { qn[(B_QTF + k) * cap] = q.qtf[k]; qn[(B_SDIAG + k) * cap] = q.sdiag[k]; }
+#undef KB_GNORM
 #pragma unroll
                     for (int i = 0; i < FSQ_NP; i++)
 #pragma unroll
