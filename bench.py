@@ -379,7 +379,7 @@ def extras(a, torch, E, N, pflib, imgs, d_img, prm, dev):
     n = min(a.steps, 6)
     pinned = torch.from_numpy(imgs.view(np.int16)).pin_memory()
     bufs = [torch.empty_like(d_img) for _ in range(3)]
-    pipe = E.StreamPipeline(a.fields, a.size, a.size, depth=a.depth, inject_below=a.inject_below, device=dev)
+    pipe = E.StreamPipeline(a.fields, a.size, a.size, depth=min(a.depth, 8), inject_below=a.inject_below, device=dev)
 
     def jobs(k):
         for j in range(k):
