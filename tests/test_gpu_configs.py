@@ -97,6 +97,38 @@ def test_config2_full_size_replicated_golden(env):
     assert (keep - (np.arange(n) * ncand)[:, None] == keep[0][None]).all()  # same kept candidates in the same order
 
 
+def test_config2_full_size_through_the_bench_pipeline(env):
+    """bench.py's default path at its full size: three steps of 1 024 fields of 512x512 streamed through
+    engine.StreamPipelineGroup (two fit queues, continuous batching; 13 M LM solves).  Every field is a copy of golden
+    field f1, so every field of every step must reproduce the reference's recorded fits and kept table."""
+    torch, N, E, pflib, pc, synth, O = env
+    g, img = load_field("f1_cfg2_512_500")
+    n = 1024
+    d_img = E.to_device_u16(img[None]).expand(n, -1, -1).contiguous()
+    prm = E.detect_params(5, pflib.default_correlation_matrix, 2)
+    ncand, nk = len(g["candidates"]), len(g["table_keys"])
+    group = E.StreamPipelineGroup(n, 512, 512, queues=2, depth=6)
+    seen = []
+
+    def on_done(j, k, eng, total):
+        nf = eng.n_fields
+        assert total == nf * ncand
+        rows = eng.rows[:total].cpu().numpy().view(N.ROW_DTYPE).reshape(nf, ncand)
+        p = np.stack([rows[c] for c in ("H", "A", "p2", "p3", "sigma_h", "sigma_w", "theta")], axis=-1)
+        assert bits_equal(p[0], g["params"]).all() and (p.view(np.uint64) == p[0].view(np.uint64)[None]).all()
+        assert (rows["status"] == g["status"][None]).all() and (rows["nfev"] == g["nfev"][None]).all()
+        table, offs = eng.kept_table()
+        assert (np.diff(offs.cpu().numpy()) == nk).all()
+        t = table.cpu().numpy().view(N.ROW_DTYPE).reshape(nf, nk)
+        assert (t["key_h"] == g["table_keys"][None, :, 0]).all() and (t["key_w"] == g["table_keys"][None, :, 1]).all()
+        seen.append((j, k))
+
+    totals = group.run([(d_img, prm)] * 3, on_done)
+    group.close()
+    assert totals == [n * ncand] * 3 and sorted(seen) == [(j, k) for j in range(3) for k in range(2)]
+    assert N.lib().fsq_fit_last_slow_count() == 0
+
+
 def test_config4_per_rank_share_2048_fields(env):
     """configs[3] (16 384 fields over 8 GPUs) gives every rank 2 048 fields of 512x512: that share in ONE engine pass
     (8.7 M LM solves), every field a copy of golden field f1, so every field must reproduce the reference's table."""
