@@ -285,14 +285,47 @@ def save_psfs_csv(psfs, image_path=None, timestamp_epoch=None, output_path=None)
     return output_path
 
 
+def convert_image(input_path, output_path=None, output_format='png', convert_command='convert'):
+    """Convert an image into the desired format; returns the path of the converted image, None on failure
+    (pflib.py:55-90).  The reference shells out to ImageMagick's `convert`; the default command is replaced by an
+    in-process PIL conversion (16-bit TIFF -> 16-bit PNG keeps every pixel value), any other `convert_command` is
+    run as the reference runs it.  An existing file at the output path is overwritten."""
+    log = logging.getLogger()
+    if output_path is None:
+        output_path = '.'.join((input_path, output_format))
+    try:
+        if convert_command == 'convert':
+            from PIL import Image
+            with Image.open(input_path) as im:
+                im.save(output_path, format=output_format.upper())
+        else:
+            import subprocess
+            p = subprocess.Popen([convert_command, input_path, output_path], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            stdout, stderr = p.communicate()
+            if stdout:
+                log.debug(stdout)
+            if stderr:
+                log.debug(stderr)
+            p.wait()
+    except Exception as e:      # noqa: BLE001 - as the reference: log, return None
+        log.exception(e, exc_info=True)
+        output_path = None
+    return output_path
+
+
 def read_image(image_path):
-    """-> (converted_path, image array).  The reference converts non-PNG files with ImageMagick and reads
-    the PNG (pflib.py:714-746); PIL reads 16-bit TIFF/PNG directly, so no conversion is needed and
-    converted_path is the image itself (or an existing `<path>.png`, which the reference prefers)."""
+    """-> (converted_path, image array).  Reference pflib.py:714-746: an image is a PNG if and only if its suffix is
+    '.png'; for any other image an existing `<path>.png` is used, else the image is converted to `<path>.png` first
+    (convert_image) - the PNG is what is read, and what the output file names are derived from."""
     from PIL import Image
     converted_path = image_path = os.path.abspath(image_path)
-    if image_path[-4:] != '.png' and os.path.exists(image_path + '.png'):
-        converted_path += '.png'
+    if image_path[-4:] != '.png':
+        if os.path.exists(image_path + '.png'):
+            converted_path += '.png'
+        else:
+            converted_path = convert_image(image_path)
+            if converted_path is None:
+                raise IOError("cannot convert %s to PNG" % image_path)
     with Image.open(converted_path) as im:
         return converted_path, np.array(im)
 

@@ -83,14 +83,21 @@ def test_read_image_16bit(tmp_path):
     from fluorosequencingimageanalysis_amd import pflib
     _, img = load_field("f5_small_96")
     _write_tif(str(tmp_path / "a.tif"), img)
+    # a non-PNG image without a PNG sibling is converted to '<image>.png' first (pflib.py:737-745, convert_image)
     conv, arr = pflib.read_image(str(tmp_path / "a.tif"))
-    assert conv == str(tmp_path / "a.tif") and arr.dtype == np.uint16 and np.array_equal(arr, img)
+    assert conv == str(tmp_path / "a.tif.png") and os.path.exists(conv)
+    assert arr.dtype == np.uint16 and np.array_equal(arr, img)                    # 16-bit values survive the conversion
     # an existing '<image>.png' is what the reference reads instead (pflib.py:737-739)
     Image.fromarray((img // 2).astype(np.uint16)).save(str(tmp_path / "a.tif.png"))
     conv, arr = pflib.read_image(str(tmp_path / "a.tif"))
     assert conv == str(tmp_path / "a.tif.png") and np.array_equal(arr, img // 2)
+    conv, arr = pflib.read_image(conv)                                            # a PNG is read as it is
+    assert conv == str(tmp_path / "a.tif.png") and np.array_equal(arr, img // 2)
     with pytest.raises(Exception):
         pflib.read_image(str(tmp_path / "missing.tif"))
+    assert pflib.convert_image(str(tmp_path / "missing.tif")) is None             # logged, None (pflib.py:87-90)
+    out = pflib.convert_image(str(tmp_path / "a.tif"), output_path=str(tmp_path / "b.png"))
+    assert out == str(tmp_path / "b.png") and np.array_equal(np.array(Image.open(out)), img)
 
 
 @pytest.fixture
@@ -135,13 +142,15 @@ def test_image_batch_semantics(tmp_path, fake_gpu, monkeypatch, caplog):
     assert sorted(res) == [str(d / "a.tif"), str(d / "b.tif"), str(d / "c.tif")]
     conv, pkl, tab, png = res[str(d / "b.tif")]
     assert conv == str(d / "b.tif.png") and pkl == conv + "_psfs_nzaj5s.pkl" and tab == conv + "_psfs_nzaj5s.csv" and png is None
-    assert res[str(d / "a.tif")][1] == str(d / "a.tif") + "_psfs_nzaj5s.pkl"
+    assert res[str(d / "a.tif")][0] == str(d / "a.tif.png")                      # converted on the way, like the reference
+    assert res[str(d / "a.tif")][1] == str(d / "a.tif.png") + "_psfs_nzaj5s.pkl"
     for v in res.values():
         assert os.path.exists(v[1]) and os.path.exists(v[2])
         assert open(v[2]).read().splitlines()[1].split("\t")[0] == v[0]          # 'Absolute image path' = converted path
     shapes = sorted(c[0] for c in fake_gpu)
     assert shapes == [(1, 64, 80), (3, 96, 96)] and all(c[1] == {"c_std": 3} for c in fake_gpu)
-    assert len([r for r in caplog.records if r.levelno >= logging.ERROR]) == 3   # corrupt, missing, re-key
+    # corrupt and missing: logged by convert_image and again by image_batch (as in the reference); re-key: once
+    assert len([r for r in caplog.records if r.levelno >= logging.ERROR]) == 5
 
 
 def test_parallel_image_batch_validates_num_processes(fake_gpu, tmp_path):
