@@ -1,13 +1,12 @@
 #!/usr/bin/env python3
 """
-Find fluorescent spots in all images.
+Spot finding over directory trees of TIFF images, on MI355X GPUs.
 
-Will traverse all target_directories and process all found *.tif files through
-pflib.parallel_image_batch.  For each image, spot finding results are output as a Python
-pickle file and a csv file (see pflib.save_psfs_pkl and pflib.save_psfs_csv).
+Every *.tif file below the given directories goes through pflib.parallel_image_batch; per image a pickle and a tab-separated
+table of its PSFs are written next to it (pflib.save_psfs_pkl / pflib.save_psfs_csv).
 
-Drop-in for the reference's basic_image_script.py (basic_image_script.py:84-124): same options, same
-directory walk, same call into pflib - computed on MI355X GPUs.  One GPU:
+Drop-in for the reference's basic_image_script.py (basic_image_script.py:36-124: same options, same directory walk, same call
+into pflib, same log lines).  One GPU:
     python -m fluorosequencingimageanalysis_amd.basic_image_script [options] DIR [DIR ...]
 all GPUs of a node (the ranks take the place of the reference's worker processes):
     python -m torch.distributed.run --standalone --nproc-per-node 8 \\
@@ -32,20 +31,19 @@ def build_parser(timestamp_datetime):
     """The reference's command line (basic_image_script.py:36-83)."""
     p = argparse.ArgumentParser(description=__doc__, formatter_class=_Formatter)
     p.add_argument('--parameters', type=str, nargs=1, default=[None],
-                   help="Parameters for pflib's find_peptides function. Expects a Python dictionary in quotes. Example: "
-                        "--parameters=\"{'median_filter_size': 6, 'c_std': 3}\" . These parameters will override "
-                        "pflib.find_peptides defaults; anything not specified will not be affected.")
+                   help="Keyword arguments for pflib.find_peptides as a quoted Python dict literal, e.g. "
+                        "--parameters=\"{'median_filter_size': 6, 'c_std': 3}\"; whatever is not named keeps its default.")
     p.add_argument('-mc', '--monte_carlo', action='store_true', default=False,
                    help="Use Monte Carlo method to peakfit (not reproduced on the GPU: find_peptides raises "
                         "NotImplementedError for every image, which is logged like any per-image failure).")
-    p.add_argument('--N_iter', type=int, nargs=1, default=[10**3], help="Number of samples to use if using --monte_carlo.")
+    p.add_argument('--N_iter', type=int, nargs=1, default=[10**3], help="Sample count handed to find_peptides together with --monte_carlo.")
     p.add_argument('-n', '--num_processes', type=int, nargs=1, default=[None],
                    help="Number of processes to use (validated like the reference; the parallel workers here are the "
                         "ranks of the torch.distributed job).")
     default_log = os.path.join('/home', 'basic_image_script_' + str(timestamp_datetime) + '.log')
     p.add_argument('-L', '--log_path', nargs=1, default=[default_log],
-                   help="Pathname for log. If the log file already exists, further logging output is appended.")
-    p.add_argument('target_directories', nargs='+', help="Directories to process. At least one must be specified.")
+                   help="Log file (appended to when it exists).")
+    p.add_argument('target_directories', nargs='+', help="One or more directories whose trees are searched for *.tif files.")
     return p
 
 
