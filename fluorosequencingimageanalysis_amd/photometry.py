@@ -1,6 +1,5 @@
 """Spot photometry on the peak table - the per-spot metrics of flexlibrary.Spot computed for whole
 tables of spots on the GPU.  Names and arguments follow flexlibrary.py:172-230."""
-import ctypes  # noqa: F401  (kept for symmetry with the other binding modules)
 
 import numpy as np
 
