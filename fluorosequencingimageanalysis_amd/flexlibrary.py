@@ -143,6 +143,92 @@ class Spot(object):
         self.h, self.w = h, w
         self.gaussian_fit = gaussian_fit
 
+    def image_slice(self, radius=None):
+        """The Spot's square of pixels, clipped at the image borders.  flexlibrary.py:113-146."""
+        if radius is None:
+            radius = (self.size - 1) // 2
+        img = self.parent_Image.image
+        return img[max(0, self.h - radius):min(img.shape[0], self.h + radius + 1),
+                   max(0, self.w - radius):min(img.shape[1], self.w + radius + 1)]
+
+    def valid_slice(self, radius=None):
+        """Is the slice of the requested radius contained in the parent image.  flexlibrary.py:148-157."""
+        if radius is None:
+            radius = (self.size - 1) // 2
+        sl = self.image_slice(radius=radius)
+        return sl.shape[0] == sl.shape[1] == 2 * radius + 1
+
+    def simple_photometry_metric(self, return_invalid=True):
+        """Sum of the Spot's pixels.  flexlibrary.py:159-170."""
+        if not return_invalid and not self.valid_slice():
+            return None
+        return np.sum(self.image_slice())
+
+    def mexican_hat_photometry_metric(self, brim_size=6, radius=9, return_invalid=True):
+        """sum(crown) - len(crown) * median(brim) over the clipped (2 radius + 1)^2 window.  flexlibrary.py:172-210
+        (one spot through fsq_mexican_hat; photometry.mexican_hat_photometry_metric takes whole tables)."""
+        from . import photometry as _ph
+        if radius is None:
+            radius = (self.size - 1) // 2
+        if not return_invalid and not self.valid_slice(radius=radius):
+            return None
+        return _ph.mexican_hat_photometry_metric(self.parent_Image.image, [(self.h, self.w)], brim_size, radius)[0]
+
+    def gaussian_volume_photometry_metric(self, scaling=10**6, default=0, return_invalid=True):
+        """float(scaling) * A * sigma_h * sigma_w of the Gaussian fit.  flexlibrary.py:212-230."""
+        if not return_invalid and not self.valid_slice():
+            return None
+        if self.gaussian_fit is None:
+            return default
+        return float(scaling) * self.gaussian_fit[3] * self.gaussian_fit[4] * self.gaussian_fit[5]
+
+    def illumina_s_n(self):
+        """pflib.illumina_s_n of the Spot's pixels.  flexlibrary.py:319-320."""
+        from . import pflib as _pf
+        return _pf.illumina_s_n(self.image_slice())
+
+
+class Image(object):
+    """A fluorosequencing image and its Spots: the reference's Image as far as the hot path needs it
+    (flexlibrary.py:323-455): `image` (2-D array, or read from metadata['filepath'] with pflib.read_image), `metadata`,
+    `spots`, and find_gaussian_psfs, which turns pflib.find_peptides' dict into Spot objects."""
+
+    def __init__(self, image=None, metadata=None, spots=None):
+        self.metadata = metadata if metadata is not None else {}
+        if image is not None:
+            self.image = image
+        elif 'filepath' in self.metadata:
+            from . import pflib as _pf
+            self.image = _pf.read_image(self.metadata['filepath'])[1]
+        else:
+            raise AttributeError("Image.image must be defined: it was neither passed at initialization nor given a "
+                                 "filepath to be read from.")
+        self.spots = spots if spots is not None else []
+
+    def _append_spots(self, new_fits, spots_append):
+        if not spots_append:
+            self.spots = []
+        for (h, w), new_fit in new_fits.items():
+            self.spots.append(Spot(self, int(_py2_round(h)), int(_py2_round(w)), 5, gaussian_fit=new_fit))
+        return len(new_fits)
+
+    def find_gaussian_psfs(self, pflib_args=None, spots_append=True):
+        """Apply pflib.find_peptides to self.image and store the PSFs as Spots; returns their number.
+        flexlibrary.py:426-455."""
+        from . import pflib as _pf
+        return self._append_spots(_pf.find_peptides(self.image, **(pflib_args or {})), spots_append)
+
+
+def find_gaussian_psfs_batch(images, pflib_args=None, spots_append=True):
+    """Image.find_gaussian_psfs for a list of same-shaped Images in one GPU pass (pflib.find_peptides_batch);
+    returns the numbers of Spots found."""
+    from . import pflib as _pf
+    images = list(images)
+    if not images:
+        return []
+    tables = _pf.find_peptides_batch(np.stack([np.asarray(im.image) for im in images]), **(pflib_args or {}))
+    return [im._append_spots(t, spots_append) for im, t in zip(images, tables)]
+
 
 class Experiment(object):
     """The static tracking helpers of the reference's Experiment class."""
