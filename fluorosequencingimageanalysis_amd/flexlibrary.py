@@ -320,3 +320,34 @@ class Experiment(object):
         flat = [s for fr in frame_spots for s in fr]
         traces = [[(flat[i] if i >= 0 else None) for i in row] for row in res[0]]
         return traces, res[1]
+
+
+class SequenceExperiment(Experiment):
+    """A sequence of frames of one field: the reference's SequenceExperiment as far as registration and tracking go
+    (flexlibrary.py:1680-1810): `peptide_frames` / `alignment_frames` (Images), `offsets`, `spot_traces`."""
+
+    def __init__(self, peptide_frames, alignment_frames=None, offsets=None, spot_traces=None, num_discarded_spots=0,
+                 photometry_adjustments=None):
+        self.peptide_frames = peptide_frames
+        self.alignment_frames = alignment_frames
+        self.offsets = offsets
+        self.spot_traces = spot_traces
+        self.num_discarded_spots = num_discarded_spots
+        self.photometry_adjustments = photometry_adjustments
+
+    def offsets_from_frames(self, upsample_factor=20):
+        """Frame-to-frame alignment by phase correlation, all pairs in one GPU call.  flexlibrary.py:1717-1741."""
+        from . import phase_correlate as _pc
+        if self.alignment_frames is None:
+            raise AttributeError("Calling offsets_from_frames without alignment_frames defined.")
+        self.offsets = _pc.offsets_from_frames(self.alignment_frames, upsample_factor=upsample_factor)
+        return self.offsets
+
+    def trace_existing_spots(self, spot_radius=None):
+        """greedy_particle_tracking over the Spots the frames already hold.  flexlibrary.py:1770-1809."""
+        if spot_radius is not None:
+            raise NotImplementedError("spot_radius currently not implemented")
+        self.spot_traces, self.num_discarded_spots = Experiment.greedy_particle_tracking(
+            frame_spots=[image.spots for image in self.peptide_frames], frame_shape=self.peptide_frames[0].image.shape,
+            offsets=self.offsets, spot_radius=0)
+        return self.spot_traces

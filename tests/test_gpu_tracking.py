@@ -195,3 +195,10 @@ def test_image_and_spot_surface(env):
     tr, nd = fl.Experiment.greedy_particle_tracking([im_.spots for im_ in imgs], imgs[0].image.shape, offsets=offsets)
     flat = [s for im_ in imgs for s in im_.spots]
     assert nd == discarded and [[(-1 if s is None else flat.index(s)) for s in row] for row in tr] == traces.tolist()
+    # SequenceExperiment: registration (== the reference's phase_correlate tuples behind the golden offsets) + tracking
+    ex = fl.SequenceExperiment(peptide_frames=imgs, alignment_frames=imgs)
+    assert [(float(a), float(b)) for a, b in ex.offsets_from_frames(upsample_factor=20)] == [(float(a), float(b)) for a, b in offsets]
+    tr2 = ex.trace_existing_spots()
+    assert ex.num_discarded_spots == discarded and [[(-1 if s is None else flat.index(s)) for s in row] for row in tr2] == traces.tolist()
+    with pytest.raises(AttributeError):
+        fl.SequenceExperiment(peptide_frames=imgs).offsets_from_frames()
