@@ -80,18 +80,16 @@ FSQ_DEV double fsq_exp_core(double x, double xtail)
 
 FSQ_DEV double fsq_exp(double x) { return fsq_exp_core<false>(x, 0.0); }
 
-// Branch-free exp for |x| < 512 (and exact for tiny / huge / non-finite x): the same operations as
-// fsq_exp_core on its main path, with the rare paths folded in by selects so that 25 pixels form ONE basic
-// block (independent dependency chains overlap in the VALU pipeline).  512 <= |x| < 1024 would need the
-// subnormal/overflow fix-up of e_exp.c's specialcase(): the LM model never gets there (sigma >= 0.75 and
-// centres in [2,3] bound the exponent by 64), so that range only raises *bad and the caller redoes the fit
-// with fsq_exp.
+// Branch-free exp for |x| < 512: fsq_exp_core's main path and nothing else, so that the pixels of a model evaluation
+// form ONE basic block (independent dependency chains overlap in the VALU pipeline).  The main path is also what e_exp.c
+// computes for tiny arguments (|x| < 2^-54, incl. +-0: there it returns 1 + x, and scale + scale * tmp with scale = 1,
+// |tmp| <= |x| rounds to the same 1); 512 <= |x| would need the subnormal / overflow fix-ups of specialcase() or the
+// inf / nan returns.  The LM model never gets there (sigma >= 0.75 and centres in [2, 3] bound the exponent by 64), so
+// anything outside |x| < 512 (NaN included) only raises *bad and the caller redoes the fit with fsq_exp.
+// fsq_selftest_exp compares the two over the whole double range.
 FSQ_DEV double fsq_exp_bf(double x, bool* bad)
 {
-    const unsigned abstop = (unsigned)(fsq_bits(x) >> 52) & 0x7ff;
-    const bool tiny = (abstop - 0x3c9u) >= 0x80000000u;            // |x| < 2^-54 (incl. +-0)
-    const bool big = abstop >= 0x409u;                             // |x| >= 1024, inf, nan
-    *bad = *bad || (abstop == 0x408u);
+    *bad = *bad || !(__builtin_fabs(x) < 512.0);
     double kd = fsq_fma(x, EXP_INVLN2N, EXP_SHIFT);
     unsigned long long ki = fsq_bits(kd);
     kd -= EXP_SHIFT;
@@ -108,47 +106,7 @@ FSQ_DEV double fsq_exp_bf(double x, bool* bad)
     double tmp = fsq_fma(p23, r2, t);
     tmp = fsq_fma(r2 * r2, p45, tmp);
     double scale = fsq_dbl(sbits);
-    double res = fsq_fma(scale, tmp, scale);
-    const double res_big = (x != x) ? (1.0 + x) : ((fsq_bits(x) >> 63) ? 0.0 : __builtin_inf());
-    res = tiny ? (1.0 + x) : res;
-    res = big ? res_big : res;
-    return res;
-}
-
-// The same function in two halves around its table look-up, so that a caller can start the look-ups of several
-// arguments (from an LDS copy of the table) before finishing any of them.
-struct FsqExpA { double x, r; unsigned long long ki; };
-FSQ_DEV unsigned fsq_exp_bf_a(double x, FsqExpA* a)      // returns the table index (in 8-byte units, even)
-{
-    double kd = fsq_fma(x, EXP_INVLN2N, EXP_SHIFT);
-    a->x = x;
-    a->ki = fsq_bits(kd);
-    kd -= EXP_SHIFT;
-    double r = fsq_fma(kd, EXP_NEGLN2HIN, x);
-    a->r = fsq_fma(kd, EXP_NEGLN2LON, r);
-    return 2u * ((unsigned)a->ki & 127u);
-}
-FSQ_DEV double fsq_exp_bf_b(const FsqExpA& a, unsigned long long tab_tail, unsigned long long tab_sbits, bool* bad)
-{
-    const double x = a.x, r = a.r;
-    const unsigned abstop = (unsigned)(fsq_bits(x) >> 52) & 0x7ff;
-    const bool tiny = (abstop - 0x3c9u) >= 0x80000000u;
-    const bool big = abstop >= 0x409u;
-    *bad = *bad || (abstop == 0x408u);
-    double tail = fsq_dbl(tab_tail);
-    unsigned long long sbits = tab_sbits + (a.ki << 45);
-    double r2 = r * r;
-    double p23 = fsq_fma(EXP_C3, r, EXP_C2);
-    double p45 = fsq_fma(r, EXP_C5, EXP_C4);
-    double t = r + tail;
-    double tmp = fsq_fma(p23, r2, t);
-    tmp = fsq_fma(r2 * r2, p45, tmp);
-    double scale = fsq_dbl(sbits);
-    double res = fsq_fma(scale, tmp, scale);
-    const double res_big = (x != x) ? (1.0 + x) : ((fsq_bits(x) >> 63) ? 0.0 : __builtin_inf());
-    res = tiny ? (1.0 + x) : res;
-    res = big ? res_big : res;
-    return res;
+    return fsq_fma(scale, tmp, scale);
 }
 
 // ---- division by a shared divisor --------------------------------------------------------------------------

@@ -19,6 +19,7 @@
 // Arithmetic: identical, operation for operation, to fsq_lm_core.h (the reference's mpfit order); where an
 // operation is evaluated by a cheaper instruction sequence (hoisted-reciprocal division, range-specialised
 // 0.5/sqrt) the sequence is the compiler's own with its no-op wrappers removed - see fsq_devmath.h.
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 
@@ -36,10 +37,10 @@ namespace {
                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 #ifdef FSQ_PHASE_PROFILE
-__device__ unsigned long long g_rphase[16];
-#define RPH_DECL unsigned long long rph_t0 = clock64(), rph_acc[8] = {0,0,0,0,0,0,0,0};
+__device__ unsigned long long g_rphase[32];
+#define RPH_DECL unsigned long long rph_t0 = clock64(), rph_acc[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};
 #define RPH_MARK(k) { unsigned long long t_ = clock64(); rph_acc[k] += t_ - rph_t0; rph_t0 = t_; }
-#define RPH_FLUSH(off) if (threadIdx.x == 0) { for (int k_ = 0; k_ < 8; k_++) atomicAdd(&g_rphase[(off) + k_], rph_acc[k_]); }
+#define RPH_FLUSH(off) if (threadIdx.x == 0) { for (int k_ = 0; k_ < 16; k_++) atomicAdd(&g_rphase[(off) + k_], rph_acc[k_]); }
 #else
 #define RPH_DECL
 #define RPH_MARK(k)
@@ -53,8 +54,10 @@ __device__ unsigned long long g_rphase[16];
 //   queue B record (input of kB):  the same 21 + gnorm | ipvt | qtf[7] | sdiag[7] | R upper[28]          65 x 8 B
 //   queue C record (kB, resumed):  the same 65 + parl paru fp | lmpar iterations done                    69 x 8 B
 //   slow queue (plain-division kA): copies of queue-A records of fits that left the guarded operand ranges
-// Indexed by candidate: a compact 64-byte copy of the 25 ROI pixels (kinit), fvec[25] (written on acceptance,
-// read by kA), the final result, the ROI statistics.
+// Indexed by candidate: a compact 64-byte copy of the 25 ROI pixels (kinit), the model's 25 exponentials E at the current
+// point (written on acceptance, read by kA, which rebuilds fvec = data - (x0 + x1 E) from them), the final result, the ROI
+// statistics.
+enum { Q_EPS = Q_WA3 };           // kA, during qrfac: relative error bounds of the tracked column norms (by logical position)
 enum { A_IDX = 0, A_X = 1, A_DIAG = 8, A_LLIM1 = 15, A_FNORM = 16, A_PAR = 17, A_DELTA = 18, A_XNORM = 19, A_ITER = 20,
        A_LEN = 21,
        B_GNORM = 21, B_IPVT = 22, B_QTF = 23, B_SDIAG = 30, B_R = 37, B_LEN = 65,
@@ -74,7 +77,7 @@ struct FitStat {              // by candidate: ROI statistics (kinit)
 // The round kernels only ever see slots - fits of several batches share the queues and the launches.
 struct Ctx {
     uint16_t* roi;            // [pool][32]: the 25 pixels of every ROI, gathered once by kinit (64 bytes per fit)
-    double* fvec;             // [pool][25]
+    double* fvec;             // [pool][25]: E = exp(-(u^2 + v^2) / 2) of the 25 model pixels at the current x (fvec = data - (x0 + x1 E))
     FitOut* out;              // [pool]
     FitStat* stat;            // [pool]
     long long cap;            // queue capacity (positions)
@@ -122,6 +125,36 @@ FSQ_DEV void wave_mark_done(int* done, bool term, int ticket)
     }
 }
 
+// Queue records, the compact ROI copies and the by-candidate E arrays are each read once per round and written once: they
+// are accessed with NON-TEMPORAL loads / stores so that this stream (tens of KB per wave) does not evict the few KB of
+// look-up tables (exp, pow's log, sin/cos) every lane of every wave keeps coming back to from the 32 KB vector L1.
+#ifndef FSQ_NT
+#define FSQ_NT 0
+#endif
+typedef unsigned fsq_u4v __attribute__((ext_vector_type(4)));
+FSQ_DEV double nt_ld(const double* p) { return FSQ_NT ? __builtin_nontemporal_load(p) : *p; }
+FSQ_DEV void nt_st(double* p, double v) { if (FSQ_NT) __builtin_nontemporal_store(v, p); else *p = v; }
+FSQ_DEV uint4 nt_ld4(const void* p)
+{
+    const fsq_u4v v = FSQ_NT ? __builtin_nontemporal_load((const fsq_u4v*)p) : *(const fsq_u4v*)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+FSQ_DEV void nt_st4(void* p, uint4 w)
+{
+    fsq_u4v v; v.x = w.x; v.y = w.y; v.z = w.z; v.w = w.w;
+    if (FSQ_NT) __builtin_nontemporal_store(v, (fsq_u4v*)p); else *(fsq_u4v*)p = v;
+}
+struct NtRef {
+    double* p;
+    FSQ_DEV operator double() const { return nt_ld(p); }
+    FSQ_DEV void operator=(double v) const { nt_st(p, v); }
+};
+struct NtQ {        // a queue record (structure of arrays: field f of the record lives at p[f * cap])
+    double* p;
+    FSQ_DEV NtRef operator[](long long i) const { return NtRef{p + i}; }
+};
+FSQ_DEV NtQ ntq(const double* p) { return NtQ{const_cast<double*>(p)}; }
+
 FSQ_DEV int tag_slot(const Ctx& c, int tag) { return (int)((unsigned)tag & ((1u << c.tshift) - 1u)); }
 FSQ_DEV int tag_ticket(const Ctx& c, int tag) { return (int)((unsigned)tag >> c.tshift); }
 
@@ -147,8 +180,8 @@ FSQ_DEV void roi_pixels(const BatchArgs& c, long long idx, double* d)
 // the 25 pixels of fit idx from the compact copy (one 64-byte line instead of five image rows)
 FSQ_DEV void roi_compact(const Ctx& c, long long idx, double* d)
 {
-    const uint4* src = (const uint4*)(c.roi + (size_t)idx * 32);
-    const uint4 a = src[0], b = src[1], e = src[2], f = src[3];
+    const uint16_t* src = c.roi + (size_t)idx * 32;
+    const uint4 a = nt_ld4(src), b = nt_ld4(src + 8), e = nt_ld4(src + 16), f = nt_ld4(src + 24);
     const unsigned w[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, e.x, e.y, e.z, e.w, f.x, f.y, f.z, f.w};
 #pragma unroll
     for (int k = 0; k < FSQ_NPIX; k++) d[k] = (double)((w[k >> 1] >> (16 * (k & 1))) & 0xffffu);
@@ -171,9 +204,9 @@ __global__ void __launch_bounds__(256) kinit(Ctx c, BatchArgs b, double* __restr
             unsigned lo = (2 * k < FSQ_NPIX) ? (unsigned)v[2 * k] : 0u, hi = (2 * k + 1 < FSQ_NPIX) ? (unsigned)v[2 * k + 1] : 0u;
             w[k] = lo | (hi << 16);
         }
-        uint4* dst = (uint4*)(c.roi + (size_t)slot * 32);
-        dst[0] = make_uint4(w[0], w[1], w[2], w[3]); dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
-        dst[2] = make_uint4(w[8], w[9], w[10], w[11]); dst[3] = make_uint4(w[12], w[13], w[14], w[15]);
+        uint16_t* dst = c.roi + (size_t)slot * 32;
+        nt_st4(dst, make_uint4(w[0], w[1], w[2], w[3])); nt_st4(dst + 8, make_uint4(w[4], w[5], w[6], w[7]));
+        nt_st4(dst + 16, make_uint4(w[8], w[9], w[10], w[11])); nt_st4(dst + 24, make_uint4(w[12], w[13], w[14], w[15]));
     }
     double mx = v[0], isum = 0.0;
 #pragma unroll
@@ -190,7 +223,7 @@ __global__ void __launch_bounds__(256) kinit(Ctx c, BatchArgs b, double* __restr
     const double vmedian = v[12], vmean = isum / 25.0;
     const double llim1 = (mx - vmean) / 3.0;                               // pflib.py:207-209
     double x0[FSQ_NP] = {vmedian, mx, 2.5, 2.5, 1., 1., 0.};               // pflib.py:201-202
-    double* q = QA + pos;
+    const NtQ q = ntq(QA + pos);
     const long long cap = c.cap;
 #pragma unroll
     for (int k = 0; k < FSQ_NP; k++) {                                     // gaussfitter.py:202-204
@@ -206,33 +239,29 @@ __global__ void __launch_bounds__(256) kinit(Ctx c, BatchArgs b, double* __restr
     c.stat[slot].vmax = mx; c.stat[slot].vmean = vmean;
 }
 
-// kA's inputs for one quad, as they sit in registers between the loads and the LDS staging.  The loop of kA is
-// software-pipelined over them: the head (which fit) of the NEXT trip is requested at the top of a trip, the body
-// (that fit's pixels, residuals, x, diag) just before the hand-over stores of the trip, so both memory round trips
-// are hidden behind work instead of opening every trip.
-struct KaHead { int tag, niter, nfev; };
-struct KaBody { uint4 roi; double fv[7], x[2], dg[2], llim1; };
-FSQ_DEV KaHead ka_fetch_head(const double* qa, long long cap)
+// qrfac's norm down-dating squares a NumPy scalar, i.e. calls libm's pow(t, 2.0) (mpfit.py:1816) - a log, an exp, two
+// dependent table look-ups: a fifth of the Jacobian round's time for a number that is only ever COMPARED (pivot choice,
+// the re-computation test).  pow(t, 2.0) is the correctly rounded square unless t^2 lies within pow's own error of a
+// rounding boundary: e_pow.c bounds its error before the final rounding by ulperr_exp - 0.5 = 0.009 ulp plus
+// |y log x| * relerr_log = |2 ln t| * 1.3 * 2^-68 (< 0.002 ulp for t^2 >= 2^-300).  So with sq = RN(t * t) and
+// lo = t * t - sq (exact, one fma): |lo| <= 0.485 ulp(sq) and sq not a power of two (where the spacing changes) imply
+// pow(t, 2.0) == sq.  fsq_selftest_square checks that implication against fsq_pow2 on the GPU.
+FSQ_DEV bool fsq_square_is_pow2(double t, double sq, double lo)
 {
-    KaHead h; int dummy;
-    unpack2(qa[A_IDX * cap], &h.tag, &dummy);
-    unpack2(qa[A_ITER * cap], &h.niter, &h.nfev);
-    return h;
+    const int ex = fsq_expo(sq);                                    // sq = m * 2^ex, 0.5 <= m < 1: ulp(sq) = 2^(ex - 53)
+    const double thr = __builtin_ldexp(0.485, ex - 53);
+    const bool ok = (__builtin_fabs(lo) <= thr) && ((fsq_bits(sq) & 0xfffffffffffffull) != 0ull) && (sq >= 0x1p-300) && (sq < 0x1p300);
+    return ok || (t == 0);
 }
-FSQ_DEV KaBody ka_fetch_body(const Ctx& c, const double* qa, long long cap, int c4, int idx)
+
+// exp(-(u^2 + v^2) / 2) of one model pixel from the numerators of its two rotated offsets (gaussfitter.py:128-135)
+template <bool FAST>
+FSQ_DEV double ka_gauss(double nu, double nv, const FsqDivisor& k4, const FsqDivisor& k5, int* em, bool* bad)
 {
-    KaBody b;
-    b.roi = *(const uint4*)(c.roi + (size_t)idx * 32 + c4 * 8);
-#pragma unroll
-    for (int m = 0; m < 7; m++) { const int k = c4 + 4 * m; b.fv[m] = (k < FSQ_NPIX) ? c.fvec[(size_t)idx * FSQ_NPIX + k] : 0.0; }
-#pragma unroll
-    for (int m = 0; m < 2; m++) {
-        const int k = c4 + 4 * m;
-        b.x[m] = (k < FSQ_NP) ? qa[(A_X + k) * cap] : 0.0;
-        b.dg[m] = (k < FSQ_NP) ? qa[(A_DIAG + k) * cap] : 0.0;
-    }
-    b.llim1 = qa[A_LLIM1 * cap];
-    return b;
+    if (FAST) { *em = min(*em, fsq_expo(nu)); *em = min(*em, fsq_expo(nv)); }
+    const double u = fsq_div_sel<FAST>(nu, k4), v = fsq_div_sel<FAST>(nv, k5);
+    const double e = -(u * u + v * v) / 2.;
+    return FAST ? fsq_exp_bf(e, bad) : fsq_exp(e);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -242,15 +271,12 @@ FSQ_DEV KaBody ka_fetch_body(const Ctx& c, const double* qa, long long cap, int 
 // a copy of its queue-A record to the slow queue SQ, which the FAST = false build (plain divisions, same code) works
 // off when the host next looks (fits are independent, so a fit may fall a few rounds behind).
 // The FAST build also zeroes the queue counters of the next round (nobody reads or appends to them during kA).
-// With one trip per block (the default grid) there is no next trip to prefetch for; FSQ_KA_PIPELINE=1 compiles the
-// software pipeline back in for resident grids (FSQ_TRIPS_PER_BLOCK=0).
-#ifndef FSQ_KA_LANES_DEFAULT
-#define FSQ_KA_LANES_DEFAULT 4
-#endif
-#ifndef FSQ_KA_PIPELINE
-#define FSQ_KA_PIPELINE 0
-#endif
-static constexpr bool KA_PIPELINE = FSQ_KA_PIPELINE != 0;
+// One trip per block (the FAST = false build strides over the slow queue with a small grid).  A third of a lone trip used
+// to be memory round trips - record, then pixels / E by the slot the record names, then five scalars fetched late, then
+// the queue-B reservation at the very end - so: the whole record is fetched up front (lane c4 of the quad takes fields c4,
+// c4 + 4, ...; the scalars wait in LDS), the reservation is made at the top (a quad that turns out not to need its slot
+// leaves a DEAD record, tag -1, which the step round skips), and the parameter-only part of fdjac2 (steps, sin / cos,
+// divisors) runs while the pixels and E are on their way.
 template <bool FAST>
 __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __restrict__ QA, const int* __restrict__ cntA_p,
                                                      double* __restrict__ QB, int* __restrict__ cntB_p,
@@ -264,113 +290,189 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
     const int cntA = FAST ? *cntA_p : *slow_cnt;
     if (!FAST && blockIdx.x == 0 && threadIdx.x == 0 && cntA > 0) atomicAdd(c.slow_total, cntA);
     if (FAST && blockIdx.x == 0 && threadIdx.x < 4) next_counters[threadIdx.x] = 0;
-    double ca[FSQ_NPIX], cb[FSQ_NPIX], refl[FSQ_NPIX];
+    double ca[FSQ_NPIX], cb[FSQ_NPIX];
     RPH_DECL
     const long long cap = c.cap;
     const int stride = gridDim.x * 16;
-    // pipeline prologue: head and body of this wave's first trip
-    KaHead hd = {0, 1, 0};
-    KaBody bd = {};
-    int qpos = 0;
-    if (KA_PIPELINE) {
-        const int base0 = blockIdx.x * 16;
-        if (base0 + quad < cntA) {
-            qpos = base0 + quad;
-            hd = ka_fetch_head(QA + qpos, cap);
-            bd = ka_fetch_body(c, QA + qpos, cap, c4, tag_slot(c, hd.tag));
-        }
-    }
-    for (int base = blockIdx.x * 16; base < cntA; base += stride) {
+    int base = blockIdx.x * 16;
+    if (base >= cntA) return;
+    do {
         RPH_MARK(0)
         const bool active = (base + quad) < cntA;
-        if (!KA_PIPELINE && active) {           // plain loads at the top of the trip
-            qpos = base + quad;
-            hd = ka_fetch_head(QA + qpos, cap);
-            bd = ka_fetch_body(c, QA + qpos, cap, c4, tag_slot(c, hd.tag));
-        }
-        const double* qa = QA + qpos;
-        // head of the next trip: requested now, needed only at the end of this one
-        const bool activeN = KA_PIPELINE && (base + stride + quad) < cntA;
-        int qposN = 0;
-        KaHead hdN = {0, 1, 0};
-        if (activeN) {
-            qposN = base + stride + quad;
-            hdN = ka_fetch_head(QA + qposN, cap);
-        }
+        const NtQ qa = ntq(QA + (active ? base + quad : 0));
+        double rec[6];                      // fields c4, c4 + 4, ... of the 21-field queue-A record
+#pragma unroll
+        for (int m = 0; m < 6; m++) { const int f = c4 + 4 * m; rec[m] = (active && f < A_LEN) ? (double)qa[f * cap] : 0.0; }
+        int at = wave_reserve(cntB_p, active && c4 == 0);       // this quad's queue-B slot (see above)
+        at = __shfl(at, qbase);
         bool hz = false, qhz = false;     // FAST: some operand left the range in which fsq_div_by == `/`
         int emin = 0;                     // FAST: smallest exponent among the tracked numerators
-        int idx = 0, tag = 0;
+        int tag, niter, nfev, dummy_;
+        unpack2(quad_bcast(rec[0], qbase), &tag, &dummy_);      // field 0 = A_IDX, field 20 = A_ITER: both in lane 0's share
+        unpack2(quad_bcast(rec[5], qbase), &niter, &nfev);
+        const int idx = tag_slot(c, tag);
+        const bool fresh = active && (nfev == 0);
         double llim1 = 0., fnorm = 0., xnorm = 0., delta = 0., par_in = 0.;
-        int niter = 1, nfev = 0;
-        bool fresh = false;
         unsigned ipvt = 0x76543210u;
         int status = 0;
         double gnorm = 0.;
+        uint4 roi = make_uint4(0u, 0u, 0u, 0u);
+        double ev[7];
+#pragma unroll
+        for (int m = 0; m < 7; m++) ev[m] = 0.0;
+        if (active) {                       // pixels and E by pool slot: on their way while the parameters are worked on
+            roi = nt_ld4(c.roi + (size_t)idx * 32 + c4 * 8);
+            if (!fresh) {
+#pragma unroll
+                for (int m = 0; m < 7; m++) { const int k = c4 + 4 * m; if (k < FSQ_NPIX) ev[m] = nt_ld(c.fvec + (size_t)idx * FSQ_NPIX + k); }
+            }
+#pragma unroll
+            for (int m = 0; m < 6; m++) {   // fields 1..19 -> LDS slots 0..18: x | diag | llim1 fnorm par delta xnorm (Q_X, Q_DIAG, Q_TMP[0..4])
+                const int f = c4 + 4 * m;
+                if (f >= 1 && f <= 19) QL(Q_X, f - 1) = rec[m];
+            }
+        }
+        WAVE_SYNC();
+        RPH_MARK(1)
         if (active) {
-            tag = hd.tag; idx = tag_slot(c, tag); niter = hd.niter; nfev = hd.nfev;
-            fresh = (nfev == 0);        // llim1 goes to LDS below; fnorm, par, delta, xnorm are fetched when first needed
-            {   // lane c4 of the quad converts pixels 8*c4 .. 8*c4+7 of the compact ROI copy
-                const uint4 pw = bd.roi;
-                const unsigned w[4] = {pw.x, pw.y, pw.z, pw.w};
+            // ---- fdjac2 (mpfit.py:1512-1612): slot s = column s of the Jacobian, slot 7 = f(x) itself -------------
+            // The model is g = p0 + p1 * E with E = exp(-(u^2 + v^2) / 2) a function of p2..p6 only, so the columns of p0
+            // and p1 and f(x) itself need no new exp: they follow from E at the current point, which is what the step
+            // round leaves in c.fvec (fvec = data - (x0 + x1 * E) is rebuilt from it with the operations that produced it).
+            // The five columns that do need the model (c2, c3, sigma4, sigma5, theta) are evaluated split by PIXEL over the
+            // quad - lane c4 takes pixels c4, c4 + 4, ... for every column - and handed to the lanes that own the columns
+            // through the staging slots: 35 pixel evaluations per lane in lock step instead of 50.
+            double xx[FSQ_NP], hh[FSQ_NP];
+#pragma unroll
+            for (int k = 0; k < FSQ_NP; k++) {
+                xx[k] = QL(Q_X, k);
+                const double eps = 1.4901161193847656e-08;
+                double h_ = eps * __builtin_fabs(xx[k]);
+                if (h_ == 0) h_ = eps;
+                const double ul = k < 2 ? 0.0 : k < 4 ? 3.0 : k < 6 ? 2.0 : 360.0;
+                if (k >= 2 && (xx[k] > ul - h_)) h_ = -h_;                   // mpfit.py:1582-1587
+                hh[k] = h_;
+            }
+            bool bad = false;
+            double sn, cs;
+            fsq_sincos(FSQ_PI_180 * xx[6], &sn, &cs);
+            const double rcx = xx[3] * cs - xx[2] * sn, rcy = xx[3] * sn + xx[2] * cs;
+            const FsqDivisor k4 = fsq_divisor(xx[4]), k5 = fsq_divisor(xx[5]);
+            if (FAST)       // |numerator| <= |p2| + |p3| + 8: bounded once the centre is
+                hz = hz || !fsq_divisor_in_range(xx[4]) || !fsq_divisor_in_range(xx[5]) || !(__builtin_fabs(xx[2]) <= 0x1p100) ||
+                     !(__builtin_fabs(xx[3]) <= 0x1p100);
+            {   // the pixels and E have arrived by now: lane c4 of the quad converts pixels 8 c4 .. 8 c4 + 7 of the ROI copy
+                const unsigned w[4] = {roi.x, roi.y, roi.z, roi.w};
 #pragma unroll
                 for (int t = 0; t < 8; t++) {
                     const int k = c4 * 8 + t;
                     if (k < FSQ_NPIX) QL(Q_DATA, k) = (double)((w[t >> 1] >> (16 * (t & 1))) & 0xffffu);
                 }
-            }
-            if (!fresh) {
+                if (!fresh) {
 #pragma unroll
-                for (int m = 0; m < 7; m++) { const int k = c4 + 4 * m; if (k < FSQ_NPIX) QL(Q_FVEC, k) = bd.fv[m]; }
-            }
-#pragma unroll
-            for (int m = 0; m < 2; m++) { const int k = c4 + 4 * m; if (k < FSQ_NP) { QL(Q_X, k) = bd.x[m]; QL(Q_DIAG, k) = bd.dg[m]; } }
-            if (c4 == 0) QL(Q_TMP, 6) = bd.llim1;
-        }
-        WAVE_SYNC();
-        RPH_MARK(1)
-        if (active) {
-            // ---- fdjac2 (mpfit.py:1512-1612): slot s = column s of the Jacobian, slot 7 = f(x) itself ---
-            double hA = 0., hB = 0.;
-#pragma unroll 1
-            for (int pass = 0; pass < 2; pass++) {       // rolled on purpose: one copy of the model code (I-cache)
-                const int slot = c4 + 4 * pass;
-                asm volatile("" ::: "memory");      // keep the pixel reads inside the pass (hoisted they cost 50 VGPRs)
-                double xp[FSQ_NP];          // x is re-read from LDS where needed rather than kept in registers
-#pragma unroll
-                for (int k = 0; k < FSQ_NP; k++) xp[k] = QL(Q_X, k);
-                double hh = 0.;
-                if (slot < 7) {
-                    const double xs = QL(Q_X, slot);
-                    const double eps = 1.4901161193847656e-08;
-                    hh = eps * __builtin_fabs(xs);
-                    if (hh == 0) hh = eps;
-                    double ul = slot < 2 ? 0.0 : slot < 4 ? 3.0 : slot < 6 ? 2.0 : 360.0;
-                    if (slot >= 2 && (xs > ul - hh)) hh = -hh;
-#pragma unroll
-                    for (int k = 0; k < FSQ_NP; k++) xp[k] = (slot == k) ? (xp[k] + hh) : xp[k];
+                    for (int m = 0; m < 7; m++) { const int k = c4 + 4 * m; if (k < FSQ_NPIX) QL(Q_FVEC, k) = ev[m]; }
                 }
-                quad_residual_regs<FAST>(lds, quad, xp, refl, &emin, &hz);   // refl is free here: the staging column
-                if (pass == 0) {
-                    hA = hh;
-#pragma unroll
-                    for (int i = 0; i < FSQ_NPIX; i++) ca[i] = refl[i];
-                } else {
-                    hB = hh;
-#pragma unroll
-                    for (int i = 0; i < FSQ_NPIX; i++) cb[i] = refl[i];
-                }
-            }
-            RPH_MARK(2)
-            if (fresh) {                    // mpfit's first function call (mpfit.py:999): fvec = f(x0)
-                if (c4 == 3) {
-#pragma unroll
-                    for (int i = 0; i < FSQ_NPIX; i++) { QL(Q_FVEC, i) = cb[i]; c.fvec[(size_t)idx * FSQ_NPIX + i] = cb[i]; }
-                }
-                nfev = 1;
             }
             WAVE_SYNC();
+            if (__ballot(fresh)) {          // mpfit's first function call (mpfit.py:999): E at x0 (whole batches are fresh together)
+                if (fresh) {
+#pragma unroll 1
+                    for (int m = 0; m < 7; m++) {
+                        const int i = c4 + 4 * m;
+                        if (i < FSQ_NPIX) {
+                            const int xi = i / 5;
+                            const double x = (double)xi, y = (double)(i - 5 * xi);
+                            const double xp = x * cs - y * sn, yp = x * sn + y * cs;
+                            const double E = ka_gauss<FAST>(rcx - xp, rcy - yp, k4, k5, &emin, &bad);
+                            QL(Q_FVEC, i) = E;
+                            nt_st(c.fvec + (size_t)idx * FSQ_NPIX + i, E);
+                        }
+                    }
+                }
+                WAVE_SYNC();
+            }
+            if (fresh) nfev = 1;
+            {   // phase A: the columns of p0, p1 (from E, by their owners) and of the centre (c2, c3: by pixel)
+                const double x2p = xx[2] + hh[2], x3p = xx[3] + hh[3];
+                const double rcx2 = xx[3] * cs - x2p * sn, rcy2 = xx[3] * sn + x2p * cs;
+                const double rcx3 = x3p * cs - xx[2] * sn, rcy3 = x3p * sn + xx[2] * cs;
+                if (FAST) hz = hz || !(__builtin_fabs(x2p) <= 0x1p100) || !(__builtin_fabs(x3p) <= 0x1p100);
+#pragma unroll 1
+                for (int m = 0; m < 7; m++) {
+                    const int i = c4 + 4 * m;
+                    if (i < FSQ_NPIX) {
+                        const int xi = i / 5;
+                        const double x = (double)xi, y = (double)(i - 5 * xi);
+                        const double xp = x * cs - y * sn, yp = x * sn + y * cs;
+                        const double d = QL(Q_DATA, i);
+                        const double E2 = ka_gauss<FAST>(rcx2 - xp, rcy2 - yp, k4, k5, &emin, &bad);
+                        const double E3 = ka_gauss<FAST>(rcx3 - xp, rcy3 - yp, k4, k5, &emin, &bad);
+                        QL(Q_STAGE, i) = d - (xx[0] + xx[1] * E2);
+                        QL(Q_STAGE + 25, i) = d - (xx[0] + xx[1] * E3);
+                    }
+                }
+                const double p0 = (c4 == 0) ? xx[0] + hh[0] : xx[0], p1 = (c4 == 1) ? xx[1] + hh[1] : xx[1];
+#pragma unroll
+                for (int i = 0; i < FSQ_NPIX; i++) ca[i] = QL(Q_DATA, i) - (p0 + p1 * QL(Q_FVEC, i));
+                WAVE_SYNC();
+                if (c4 >= 2) {
+#pragma unroll
+                    for (int i = 0; i < FSQ_NPIX; i++) ca[i] = QL(Q_STAGE + 25 * (c4 - 2), i);
+                }
+                // every lane has read E: fvec = f(x) takes its place (each lane its own pixels)
+                double fvm[7];
+#pragma unroll
+                for (int m = 0; m < 7; m++) {
+                    const int i = c4 + 4 * m;
+                    fvm[m] = (m < 6 || i < FSQ_NPIX) ? QL(Q_DATA, i) - (xx[0] + xx[1] * QL(Q_FVEC, i)) : 0.0;
+                }
+                WAVE_SYNC();
+#pragma unroll
+                for (int m = 0; m < 7; m++) {
+                    const int i = c4 + 4 * m;
+                    if (m < 6 || i < FSQ_NPIX) QL(Q_FVEC, i) = fvm[m];
+                }
+            }
+            {   // phase B: the columns of sigma4, sigma5 (one new quotient each) and theta (a new rotation), by pixel
+                const double x4p = xx[4] + hh[4], x5p = xx[5] + hh[5];
+                const FsqDivisor k4p = fsq_divisor(x4p), k5p = fsq_divisor(x5p);
+                double snt, cst;
+                fsq_sincos(FSQ_PI_180 * (xx[6] + hh[6]), &snt, &cst);
+                const double rcxt = xx[3] * cst - xx[2] * snt, rcyt = xx[3] * snt + xx[2] * cst;
+                if (FAST) hz = hz || !fsq_divisor_in_range(x4p) || !fsq_divisor_in_range(x5p);
+#pragma unroll 1
+                for (int m = 0; m < 7; m++) {
+                    const int i = c4 + 4 * m;
+                    if (i < FSQ_NPIX) {
+                        const int xi = i / 5;
+                        const double x = (double)xi, y = (double)(i - 5 * xi);
+                        const double xp = x * cs - y * sn, yp = x * sn + y * cs;
+                        const double nu = rcx - xp, nv = rcy - yp;
+                        if (FAST) { emin = min(emin, fsq_expo(nu)); emin = min(emin, fsq_expo(nv)); }
+                        const double ub = fsq_div_sel<FAST>(nu, k4), vb = fsq_div_sel<FAST>(nv, k5);
+                        const double u4 = fsq_div_sel<FAST>(nu, k4p), v5 = fsq_div_sel<FAST>(nv, k5p);
+                        const double e4 = -(u4 * u4 + vb * vb) / 2., e5 = -(ub * ub + v5 * v5) / 2.;
+                        const double E4 = FAST ? fsq_exp_bf(e4, &bad) : fsq_exp(e4);
+                        const double E5 = FAST ? fsq_exp_bf(e5, &bad) : fsq_exp(e5);
+                        const double xpt = x * cst - y * snt, ypt = x * snt + y * cst;
+                        const double Et = ka_gauss<FAST>(rcxt - xpt, rcyt - ypt, k4, k5, &emin, &bad);
+                        const double d = QL(Q_DATA, i);
+                        QL(Q_STAGE, i) = d - (xx[0] + xx[1] * E4);
+                        QL(Q_STAGE + 25, i) = d - (xx[0] + xx[1] * E5);
+                        QL(Q_STAGE + 50, i) = d - (xx[0] + xx[1] * Et);
+                    }
+                }
+                WAVE_SYNC();
+#pragma unroll
+                for (int i = 0; i < FSQ_NPIX; i++) cb[i] = QL((c4 < 3) ? Q_STAGE + 25 * c4 : Q_FVEC, i);
+            }
+            if (FAST) hz = hz || bad;
+            const double hA = (c4 == 0) ? hh[0] : (c4 == 1) ? hh[1] : (c4 == 2) ? hh[2] : hh[3];
+            const double hB = (c4 == 0) ? hh[4] : (c4 == 1) ? hh[5] : (c4 == 2) ? hh[6] : 0.0;
+            RPH_MARK(2)
+            if (fresh && c4 == 0) QL(Q_TMP, 1) = fsq_sqrt(lds_dot25(lds, quad, Q_FVEC));     // fnorm of a fresh fit
             nfev += 7;
-            if (fresh) QL(Q_TMP, 5) = fsq_sqrt(lds_dot25(lds, quad, Q_FVEC));     // fnorm of a fresh fit
+            WAVE_SYNC();            // (the staging slots are free again: qrfac writes Q_ACN .. Q_R below)
             bool pegA = false, pegB = false;
             {
                 double sA = 0.0, sB = 0.0;
@@ -393,13 +495,13 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                 }
                 {   // pegged parameters (mpfit.py:1073-1091)
                     const int slot = c4;
-                    const double xs = QL(Q_X, slot), llim1 = QL(Q_TMP, 6);
+                    const double xs = QL(Q_X, slot), llim1 = QL(Q_TMP, 0);
                     bool lp = (xs == fsq_llim(slot, llim1)), up = fsq_qulim(slot) && (xs == fsq_ulim(slot));
                     pegA = (lp && sA > 0) || (up && sA < 0);
                 }
                 if (c4 < 3) {
                     const int slot = c4 + 4;
-                    const double xs = QL(Q_X, slot), llim1 = QL(Q_TMP, 6);
+                    const double xs = QL(Q_X, slot), llim1 = QL(Q_TMP, 0);
                     bool lp = (xs == fsq_llim(slot, llim1)), up = (xs == fsq_ulim(slot));
                     pegB = (lp && sB > 0) || (up && sB < 0);
                 }
@@ -413,10 +515,10 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
             // ---- qrfac with column pivoting (mpfit.py:1748-1822), Q^T f fused in as slot 7 ----------
             {
                 double nA = fsq_sqrt(dot_regcol(ca, 25));
-                QL(Q_ACN, c4) = nA; QL(Q_RDIAG, c4) = nA; QL(Q_WA, c4) = nA;
+                QL(Q_ACN, c4) = nA; QL(Q_RDIAG, c4) = nA; QL(Q_WA, c4) = nA; QL(Q_EPS, c4) = 0.;
                 if (c4 < 3) {
                     double nB = fsq_sqrt(dot_regcol(cb, 25));
-                    QL(Q_ACN, c4 + 4) = nB; QL(Q_RDIAG, c4 + 4) = nB; QL(Q_WA, c4 + 4) = nB;
+                    QL(Q_ACN, c4 + 4) = nB; QL(Q_RDIAG, c4 + 4) = nB; QL(Q_WA, c4 + 4) = nB; QL(Q_EPS, c4 + 4) = 0.;
                 }
             }
             WAVE_SYNC();
@@ -430,14 +532,28 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                     int kmax = -1;
                     for (int k = n7 - 1; k >= j; k--)
                         if (QL(Q_RDIAG, k) == rmax) kmax = k;
+                    if (FAST) {
+                        // the tracked norms carry error bounds (see the down-dating below): the choice is the reference's
+                        // when every other candidate lies clearly below the chosen one (exact values compare exactly)
+                        if (kmax < 0) hz = true;
+                        else {
+                            const double em = QL(Q_EPS, kmax), low_m = rmax * (1. - em);
+                            for (int k = j; k < n7; k++) {
+                                const double ek = QL(Q_EPS, k);
+                                if (k != kmax && (ek != 0 || em != 0) && !(QL(Q_RDIAG, k) * (1. + ek) < low_m)) hz = true;
+                            }
+                        }
+                    }
                     if (kmax >= 0 && kmax != j) {
                         int sj = nib_get(ipvt, j), sk = nib_get(ipvt, kmax);
                         ipvt = nib_set(nib_set(ipvt, j, sk), kmax, sj);
                         pos = nib_set(nib_set(pos, sk, j), sj, kmax);
                         QL(Q_RDIAG, kmax) = QL(Q_RDIAG, j);
                         QL(Q_WA, kmax) = QL(Q_WA, j);
+                        if (FAST) QL(Q_EPS, kmax) = QL(Q_EPS, j);
                     }
                 }
+                RPH_MARK(7)
                 const int lj = nib_get(ipvt, j);
                 const int owner = qbase + (lj & 3);
                 const bool useB = (lj >> 2) != 0;
@@ -467,7 +583,7 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
 #pragma unroll
                             for (int i = 0; i < FSQ_NPIX; i++) t[i] = fsq_div_sel<FAST>(t[i], kn);   // rows >= len are zeros
                             t[0] = t[0] + 1;
-                            QL(Q_TMP, 0) = -ajnorm;
+                            QL(Q_TMP, 5) = -ajnorm;
                         }
                     }
 #pragma unroll
@@ -476,6 +592,7 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                 WAVE_SYNC();
                 broken = broken || (__shfl((int)brk, owner) != 0);
                 emin_s = __shfl(emin_s, owner);
+                RPH_MARK(8)
 #define REFL(i) QL(Q_DATA, i)
                 const double ajj0 = REFL(0);
                 const FsqDivisor kj = fsq_divisor(ajj0);
@@ -510,6 +627,7 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                 // column's new leading element R(j, .) from LDS: 8 passes per factorization instead of 14.  The rare full
                 // recomputation of a norm needs the column itself, so that goes back to the lane that holds it.
                 WAVE_SYNC();
+                RPH_MARK(9)
                 unsigned long long redo[2] = {0ull, 0ull};
 #pragma unroll
                 for (int sub = 0; sub < 2; sub++) {
@@ -517,12 +635,43 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                     bool need = false;
                     if (p < n7 && !broken && ajj0 != 0) {
                         double rk = QL(Q_RDIAG, p);
-                        if (rk != 0) {
+                        if (rk != 0 && !FAST) {
                             double temp = QL(Q_R, j * 7 + nib_get(ipvt, p)) / rk;
                             rk = rk * fsq_sqrt(np_max2(1. - fsq_pow2(temp), 0.));
                             temp = rk / QL(Q_WA, p);
                             if ((0.05 * temp * temp) <= FSQ_MACHEP || c.force_redo) need = true;
                             else QL(Q_RDIAG, p) = rk;
+                        }
+                        if (rk != 0 && FAST) {
+                            // The same down-dating with the square taken by one multiplication.  Where that provably is
+                            // pow(t, 2.0) (fsq_square_is_pow2) and the norm going in was exact, every operation below is the
+                            // reference's and the result is exact again (bound 0).  Otherwise the result carries a relative
+                            // error bound e1 against the reference's value, which the two decisions these norms feed - the
+                            // re-computation test here and the pivot choice of the next steps - take into account; a decision
+                            // the bound cannot settle sends the fit to the exact kernel (hz), like every other guarded range.
+                            const double U = 1.1102230246251565e-16;
+                            const double e0 = QL(Q_EPS, p);
+                            const double t = QL(Q_R, j * 7 + nib_get(ipvt, p)) / rk;
+                            const double sq = t * t, lo = fsq_fma(t, t, -sq);
+                            const bool exact = (e0 == 0) && fsq_square_is_pow2(t, sq, lo);
+                            const double v = 1. - sq;
+                            const double dv = exact ? 0. : sq * (2. * e0 + 8. * U) + 2. * U;      // bound of |v - v_ref|
+                            if (!(v == v)) hz = true;
+                            if (!exact && !(__builtin_fabs(v) > dv)) hz = true;                     // sign of 1 - t^2 not settled
+                            const double rk1 = rk * fsq_sqrt(np_max2(v, 0.));
+                            double e1 = 0.;
+                            if (!exact && v > 0) e1 = e0 + 0.6 * dv * __builtin_amdgcn_rcp(v) + 4. * U;
+                            if (!(e1 < 1e-3)) hz = true;
+                            const double temp = rk1 / QL(Q_WA, p);
+                            const double q = 0.05 * temp * temp;
+                            if (e1 == 0) need = (q <= FSQ_MACHEP);
+                            else {
+                                const double qe = 2. * e1 + 8. * U;
+                                if (q * (1. + qe) <= FSQ_MACHEP) need = true;
+                                else if (!(q * (1. - qe) > FSQ_MACHEP)) hz = true;
+                            }
+                            if (c.force_redo) need = true;
+                            if (!need) { QL(Q_RDIAG, p) = rk1; QL(Q_EPS, p) = e1; }
                         }
                     }
                     redo[sub] = __ballot(need);
@@ -538,20 +687,22 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                             const double rk = fsq_sqrt(dot_regcol_from1(col, len));
                             QL(Q_WA, k) = rk;
                             QL(Q_RDIAG, k) = rk;
+                            if (FAST) QL(Q_EPS, k) = 0.;            // an exact norm again
                         }
                     }
                 }
-                if (!broken) QL(Q_RDIAG, j) = QL(Q_TMP, 0);
+                RPH_MARK(10)
+                if (!broken) QL(Q_RDIAG, j) = QL(Q_TMP, 5);
                 QL(Q_R, j * 7 + lj) = QL(Q_RDIAG, j);               // fjac[j, lj] = rdiag[j] (mpfit.py:1123)
 #pragma unroll
                 for (int i = 0; i + 1 < FSQ_NPIX; i++) { ca[i] = ca[i + 1]; cb[i] = cb[i + 1]; }
                 ca[FSQ_NPIX - 1] = 0.0; cb[FSQ_NPIX - 1] = 0.0;
                 WAVE_SYNC();
+                RPH_MARK(11)
             }
             RPH_MARK(4)
             // ---- first iteration scaling, gradient test (mpfit.py:1099-1160) -----------------------
-            llim1 = qa[A_LLIM1 * cap]; par_in = qa[A_PAR * cap]; delta = qa[A_DELTA * cap]; xnorm = qa[A_XNORM * cap];
-            fnorm = fresh ? QL(Q_TMP, 5) : qa[A_FNORM * cap];
+            llim1 = QL(Q_TMP, 0); fnorm = QL(Q_TMP, 1); par_in = QL(Q_TMP, 2); delta = QL(Q_TMP, 3); xnorm = QL(Q_TMP, 4);
             if (niter == 1) {
 #pragma unroll
                 for (int k = 0; k < FSQ_NP; k++) {
@@ -599,22 +750,17 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
             }
         }
         wave_mark_done(c.done, active && status != 0 && c4 == 0 && !qhz, tag_ticket(c, tag));
-        // body of the next trip: on its way while this trip's results are stored
-        KaBody bdN = {};
-        if (activeN) bdN = ka_fetch_body(c, QA + qposN, cap, c4, tag_slot(c, hdN.tag));
-        // ---- ... or hand it over to the step round: one queue-B slot per surviving quad -------------------------
+        // ---- ... or hand it over to the step round (the queue-B slot reserved at the top) --------------------------------
         {
             bool go = active && (status == 0);
             if (FAST) {
                 int sat = wave_reserve(slow_cnt, qhz && c4 == 0);
                 sat = __shfl(sat, qbase);
-                if (qhz) for (int f = c4; f < A_LEN; f += 4) SQ[(size_t)sat + f * cap] = qa[f * cap];
+                if (qhz) for (int f = c4; f < A_LEN; f += 4) nt_st(SQ + (size_t)sat + f * cap, qa[f * cap]);
                 go = go && !qhz;
             }
-            int at = wave_reserve(cntB_p, go && c4 == 0);
-            at = __shfl(at, qbase);
+            const NtQ qb = ntq(QB + at);
             if (go) {
-                double* qb = QB + at;
                 for (int e = c4; e < 28; e += 4) {
                     int i = 0, rem = e;
                     while (rem >= 7 - i) { rem -= 7 - i; i++; }
@@ -632,16 +778,13 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                     qb[A_XNORM * cap] = xnorm; qb[A_ITER * cap] = pack2(niter, nfev);
                     qb[B_GNORM * cap] = gnorm; qb[B_IPVT * cap] = pack2((int)ipvt, 0);
                 }
-            }
+            } else if (active && c4 == 0) qb[A_IDX * cap] = pack2(-1, 0);        // terminated or sent to the slow queue: a dead slot
         }
         RPH_MARK(6)
-        if (!KA_PIPELINE) break;                // one trip per block: the host launches a block per 16 queue entries
-        hd = hdN; bd = bdN; qpos = qposN;
-    }
-    RPH_FLUSH(8)
+        base += stride;
+    } while (!FAST && base < cntA);
+    RPH_FLUSH(16)
 }
-
-#include "fsq_fit_rounds_ka8.h"
 
 // ---------------------------------------------------------------------------------------------------
 // kB: step round.  One lane per fit, grid-stride over list B.
@@ -659,17 +802,18 @@ static constexpr bool KB_LOOP = FSQ_KB_LOOP != 0;
 #ifndef FSQ_KB_WAVES
 #define FSQ_KB_WAVES 2
 #endif
-// The trial evaluation f(wa2) of the step round (mpfit.py:1245), residuals into the lane's LDS column.
+// The trial evaluation f(wa2) of the step round (mpfit.py:1245): E = exp(-(u^2 + v^2) / 2) of the 25 model pixels into the
+// lane's LDS column (the residuals data - (p0 + p1 * E) are formed by the caller; E is also what an accepted step leaves
+// in c.fvec for the next Jacobian round).
 // FAST: the model's two divisions per pixel share their divisors (sigma_h, sigma_w, inside [0.75, 2] by the bounds) ->
 // fsq_div_by, and exp is the branch-free fsq_exp_bf; the operand ranges in which those equal `/` and exp() bit for bit
 // are checked on the way and the return value is true when one was left - the caller then repeats the evaluation with
 // FAST = false (plain divisions, full exp; same order of operations as fsq_model, gaussfitter.py:100-136).
-// Rows are a rolled loop (a fifth of the code), so the pixels come straight from the compact ROI copy and the residuals
-// go to LDS slots - no dynamically indexed register array, no scratch.
+// Rows are a rolled loop (a fifth of the code) writing to LDS slots - no dynamically indexed register array, no scratch.
 FSQ_DEV int kb_res_slot(int i) { return i < 14 ? i : i + 7; }         // slots 14..20 hold the step vector wa1
 
 template <bool FAST>
-FSQ_DEV bool kb_trial_residual(const uint16_t* __restrict__ px, const double* p, double* myscr)
+FSQ_DEV bool kb_trial_gauss(const double* p, double* myscr)
 {
     bool bad = false;
     int em = 0;
@@ -694,16 +838,14 @@ FSQ_DEV bool kb_trial_residual(const uint16_t* __restrict__ px, const double* p,
             const double u = fsq_div_sel<FAST>(nu, k4);
             const double v = fsq_div_sel<FAST>(nv, k5);
             const double e = -(u * u + v * v) / 2.;
-            const double g = p[0] + p[1] * (FAST ? fsq_exp_bf(e, &bad) : fsq_exp(e));
-            const int i = xi * 5 + yi;
-            myscr[kb_res_slot(i) * 64] = (double)px[i] - g;
+            myscr[kb_res_slot(xi * 5 + yi) * 64] = FAST ? fsq_exp_bf(e, &bad) : fsq_exp(e);
         }
     }
     if (FAST) bad = bad || (em < -FSQ_DIV_EN);
     return bad;
 }
 
-FSQ_DEV double kb_late_load(const double* p) { asm volatile("" ::: "memory"); return *p; }
+FSQ_DEV double kb_late_load(const NtRef r) { asm volatile("" ::: "memory"); return (double)r; }
 
 template <bool ALIASED, bool RESUME>
 __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double* __restrict__ QB, const int* __restrict__ cntB_p,
@@ -722,9 +864,10 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
         bool live = (base + lane) < cntB;
         const int slot_in = live ? (base + lane) : 0;
         const long long cap = c.cap;
-        const double* qb = QB + slot_in;
+        const NtQ qb = ntq(QB + slot_in);
         int tag, dummy, niter, nfev, ipvt_i;
         unpack2(qb[A_IDX * cap], &tag, &dummy);
+        if (tag == -1) { live = false; tag = 0; }        // a slot the Jacobian round reserved and did not need (loads below stay in bounds)
         unpack2(qb[A_ITER * cap], &niter, &nfev);
         unpack2(qb[B_IPVT * cap], &ipvt_i, &dummy);
         const unsigned ipvt = (unsigned)ipvt_i;
@@ -742,7 +885,7 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
         const double llim1 = qb[A_LLIM1 * cap];
         // (gnorm is only copied through and tested once at the end: it is read where it is needed instead of being
         // carried through lmpar - the kernel is at its register limit)
-#define KB_GNORM() kb_late_load(qb + B_GNORM * cap)
+#define KB_GNORM() kb_late_load(qb[B_GNORM * cap])
         double fnorm = qb[A_FNORM * cap], par = qb[A_PAR * cap], delta = qb[A_DELTA * cap], xnorm = qb[A_XNORM * cap], fnorm1;
 #pragma unroll
         for (int k = 0; k < FSQ_NP; k++) myscr[k * 64] = q.dg[k];
@@ -754,6 +897,7 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
             QuadLmparSt st;
             if (!RESUME) {
                 quadlm_lmpar_begin<ALIASED, 64>(q, myscr, ipvt, delta, par, st);
+                RPH_MARK(7)
                 quadlm_lmpar_run<ALIASED, 64>(q, myscr, ipvt, delta, st, lm_first);
             } else {
                 int it, dm;
@@ -767,7 +911,7 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
                 const bool park = live && !st.done;
                 const int atC = wave_reserve(cntC, park);
                 if (park) {
-                    double* qn = QC + atC;
+                    const NtQ qn = ntq(QC + atC);
                     qn[A_IDX * cap] = pack2(tag, 0);
 #pragma unroll
                     for (int k = 0; k < FSQ_NP; k++) {
@@ -848,26 +992,39 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
         pnorm = fsq_sqrt(pnorm);
         if (niter == 1) delta = np_min2(delta, pnorm);
         RPH_MARK(3)
-        // trial evaluation (mpfit.py:1245)
-        double wa4[FSQ_NPIX];
+        // trial evaluation (mpfit.py:1245): E per pixel into the LDS column, then fnorm1 = enorm(data - (p0 + p1 * E)) with
+        // the residuals formed on the fly in numpy.dot's order (dot25: four strided sums of four, then an fma tail), so no
+        // 25-element residual array lives in registers
         {
             asm volatile("" ::: "memory");          // the pixels are fetched here, not carried through lmpar
-            const uint16_t* px = c.roi + (size_t)tag_slot(c, tag) * 32;
-            bool redo = kb_trial_residual<true>(px, wa2, myscr);
+            bool redo = kb_trial_gauss<true>(wa2, myscr);
 #ifdef FSQ_EXPERIMENT_TRIAL_TWICE       // marginal cost of the trial evaluation: do it again (same results)
             asm volatile("" ::: "memory");
-            redo = kb_trial_residual<true>(px, wa2, myscr) || redo;
+            redo = kb_trial_gauss<true>(wa2, myscr) || redo;
             asm volatile("" ::: "memory");
 #endif
             if (c.force_slow_mod > 0 && (tag_slot(c, tag) % c.force_slow_mod) == 0) redo = true;
             if (__ballot(redo)) {                   // (never on image data: operands far outside the guarded ranges)
-                if (redo) kb_trial_residual<false>(px, wa2, myscr);
+                if (redo) kb_trial_gauss<false>(wa2, myscr);
             }
+            const uint16_t* src = c.roi + (size_t)tag_slot(c, tag) * 32;
+            const uint4 a = nt_ld4(src), b = nt_ld4(src + 8), e = nt_ld4(src + 16), f = nt_ld4(src + 24);
+            const unsigned w[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, e.x, e.y, e.z, e.w, f.x, f.y, f.z, f.w};
+            double S[4], d = 0.0;
 #pragma unroll
-            for (int i = 0; i < FSQ_NPIX; i++) wa4[i] = myscr[kb_res_slot(i) * 64];
+            for (int i = 0; i < FSQ_NPIX; i++) {
+                const double pix = (double)((w[i >> 1] >> (16 * (i & 1))) & 0xffffu);
+                const double r = pix - (wa2[0] + wa2[1] * myscr[kb_res_slot(i) * 64]);
+                if (i < 4) S[i] = r * r;
+                else if (i < 16) S[i & 3] = S[i & 3] + r * r;
+                else {
+                    if (i == 16) d = (S[0] + S[2]) + (S[1] + S[3]);
+                    d = fsq_fma(r, r, d);
+                }
+            }
+            fnorm1 = fsq_sqrt(d);
         }
         nfev++;
-        fnorm1 = fsq_sqrt(dot25(wa4));
         RPH_MARK(4)
         double actred = -1.;
         if ((0.1 * fnorm1) < fnorm) actred = -fsq_pow2(fnorm1 / fnorm) + 1.;
@@ -912,7 +1069,7 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
                 xs = fsq_fma(t, t, xs);
             }
 #pragma unroll
-            for (int i = 0; i < FSQ_NPIX; i++) if (live) c.fvec[(size_t)tag_slot(c, tag) * FSQ_NPIX + i] = wa4[i];
+            for (int i = 0; i < FSQ_NPIX; i++) if (live) nt_st(c.fvec + (size_t)tag_slot(c, tag) * FSQ_NPIX + i, myscr[kb_res_slot(i) * 64]);
             xnorm = fsq_sqrt(xs);
             fnorm = fnorm1;
             niter = niter + 1;
@@ -950,7 +1107,7 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
             const int atA = wave_reserve(cntA_next, toA);
             const int atB = wave_reserve(cntB_next, toB);
             if (toA || toB) {
-                double* qn = toA ? (QA_next + atA) : (QB_next + atB);
+                const NtQ qn = ntq(toA ? (QA_next + atA) : (QB_next + atB));
                 qn[A_IDX * cap] = pack2(tag, 0);
 #pragma unroll
                 for (int k = 0; k < FSQ_NP; k++) { qn[(A_X + k) * cap] = xq[k]; qn[(A_DIAG + k) * cap] = q.dg[k]; }
@@ -1038,6 +1195,15 @@ __global__ void kdivcheck(const double* __restrict__ num, const double* __restri
 }
 std::atomic<long long> g_last_slow{0};
 
+__global__ void ksqcheck(const double* __restrict__ t, long long n, unsigned long long* bad)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = t[i], sq = x * x, lo = fsq_fma(x, x, -sq);
+    if (!fsq_square_is_pow2(x, sq, lo)) { atomicAdd(bad + 1, 1ull); return; }
+    if (fsq_bits(fsq_pow2(x)) != fsq_bits(sq)) atomicAdd(bad, 1ull);
+}
+
 __global__ void krotcheck(const double* __restrict__ t, long long n, unsigned long long* bad)
 {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1055,17 +1221,9 @@ __global__ void kexpcheck(const double* __restrict__ x, long long n, unsigned lo
     if (i >= n) return;
     bool flag = false;
     const double a = fsq_exp(x[i]), b = fsq_exp_bf(x[i], &flag);
-    FsqExpA h;
-    const unsigned ix = fsq_exp_bf_a(x[i], &h);
-    bool flag2 = false;
-    const double c = fsq_exp_bf_b(h, FSQ_EXP_TAB[ix], FSQ_EXP_TAB[ix + 1], &flag2);
-    const double ax = __builtin_fabs(x[i]);
-    const bool expect_flag = (ax >= 512.0 && ax < 1024.0);
-    bool wrong = (flag != expect_flag) || (flag2 != expect_flag);
-    if (!expect_flag) {
-        const bool nan_ok = (a != a) && (b != b) && (c != c);
-        wrong = wrong || (!nan_ok && (fsq_bits(a) != fsq_bits(b) || fsq_bits(a) != fsq_bits(c)));
-    }
+    const bool expect_flag = !(__builtin_fabs(x[i]) < 512.0);             // (NaN included)
+    bool wrong = (flag != expect_flag);
+    if (!expect_flag) wrong = wrong || (fsq_bits(a) != fsq_bits(b));
     if (wrong) atomicAdd(bad, 1ull);
 }
 }  // namespace
@@ -1083,6 +1241,23 @@ extern "C" int fsq_selftest_exp(const double* d_x, int64_t n, int64_t* mismatche
     FSQ_HIP_CHECK(hipStreamSynchronize(s));
     (void)hipFree(d_bad);
     *mismatches = (int64_t)h;
+    return FSQ_OK;
+}
+
+extern "C" int fsq_selftest_square(const double* d_t, int64_t n, int64_t* mismatches, int64_t* undecided, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (!d_t || !mismatches || !undecided || n < 0) return FSQ_EINVAL;
+    unsigned long long* d_bad = nullptr;
+    FSQ_HIP_CHECK(hipMalloc((void**)&d_bad, 16));
+    FSQ_HIP_CHECK(hipMemsetAsync(d_bad, 0, 16, s));
+    if (n > 0) hipLaunchKernelGGL(ksqcheck, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_t, (long long)n, d_bad);
+    unsigned long long h[2] = {0, 0};
+    FSQ_HIP_CHECK(hipMemcpyAsync(h, d_bad, 16, hipMemcpyDeviceToHost, s));
+    FSQ_HIP_CHECK(hipStreamSynchronize(s));
+    (void)hipFree(d_bad);
+    *mismatches = (int64_t)h[0];
+    *undecided = (int64_t)h[1];
     return FSQ_OK;
 }
 
@@ -1121,12 +1296,12 @@ extern "C" int fsq_selftest_division(const double* d_num, const double* d_den, i
 extern "C" int64_t fsq_fit_last_slow_count(void) { return g_last_slow.load(); }
 
 #ifdef FSQ_PHASE_PROFILE
-extern "C" int fsq_debug_rphase(unsigned long long* out16, int reset)
+extern "C" int fsq_debug_rphase(unsigned long long* out32, int reset)
 {
     unsigned long long* p = nullptr;
     if (hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_rphase)) != hipSuccess) return -1;
-    if (hipMemcpy(out16, p, 16 * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    if (reset) (void)hipMemset(p, 0, 16 * 8);
+    if (hipMemcpy(out32, p, 32 * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (reset) (void)hipMemset(p, 0, 32 * 8);
     return 0;
 }
 #endif
@@ -1145,7 +1320,6 @@ enum { CTL_SLOW_TOTAL = 8, CTL_SLOW_CNT = 9, CTL_DONE = 16, CTL_INTS = CTL_DONE 
 
 struct RoundsCfg {
     int trips = 1, lm_first = FSQ_LMPAR_FIRST, sync_mask = 3, force_slow_mod = 0, force_redo = 0, no_wave_prio = 0, trace = 0;
-    int ka_lanes = FSQ_KA_LANES_DEFAULT;               // lanes per fit in the Jacobian round: 8 (kA8_jacobian) or 4 (kA_jacobian)
     int max_rounds = 0, ka_lds_pad = 0, kb_lds_pad = 0;      // (debug: extra dynamic LDS per block = fewer waves per CU)
     long long two_pass_min = 524288, hiprio_below = 200000;
 };
@@ -1163,7 +1337,6 @@ RoundsCfg read_cfg()
     if (getenv("FSQ_NO_WAVE_PRIO")) g.no_wave_prio = 1;
     if (getenv("FSQ_DEBUG_TRACE")) g.trace = 1;
     if ((e = getenv("FSQ_DEBUG_MAX_ROUNDS")) != nullptr) g.max_rounds = atoi(e);
-    if ((e = getenv("FSQ_KA_LANES")) != nullptr && (atoi(e) == 4 || atoi(e) == 8)) g.ka_lanes = atoi(e);
     if ((e = getenv("FSQ_DEBUG_KA_LDS_PAD")) != nullptr) g.ka_lds_pad = atoi(e);
     if ((e = getenv("FSQ_DEBUG_KB_LDS_PAD")) != nullptr) g.kb_lds_pad = atoi(e);
     return g;
@@ -1320,14 +1493,8 @@ struct FsqFitQueue {
         const long long full = (long long)cus * 8;
         long long nB = boundA + boundB;
         if (nB > alive) nB = alive;
-        long long gA = (boundA + 15) / 16;          // kA: a block per trip unless built with FSQ_KA_PIPELINE
-        if (KA_PIPELINE) {
-            if (cfg.trips > 0) gA = (gA + cfg.trips - 1) / cfg.trips;
-            else if (gA > full) gA = full;
-        }
-        if (gA > 0 && cfg.ka_lanes == 8)         // (kA also zeroes the counters of set nxt)
-            hipLaunchKernelGGL(kA8_jacobian<true>, dim3((unsigned)((boundA + 7) / 8)), dim3(64), cfg.ka_lds_pad, s, c, QA[cur], cA[cur], QB[cur], cB[cur], SQ, cSlow, cA[nxt]);
-        else if (gA > 0)
+        const long long gA = (boundA + 15) / 16;    // kA: a block per trip
+        if (gA > 0)                                 // (kA also zeroes the counters of set nxt)
             hipLaunchKernelGGL(kA_jacobian<true>, dim3((unsigned)gA), dim3(64), cfg.ka_lds_pad, s, c, QA[cur], cA[cur], QB[cur], cB[cur], SQ, cSlow, cA[nxt]);
         else
             FSQ_HIP_CHECK(hipMemsetAsync(cA[nxt], 0, 4 * sizeof(int), s));
@@ -1335,10 +1502,7 @@ struct FsqFitQueue {
             // fits that left the guarded operand ranges since the host last looked: the plain-division build takes them
             // from the slow queue and appends their queue-B records to this round's
             // (the slow queue may have grown since the host looked: size for all)
-            if (cfg.ka_lanes == 8)
-                hipLaunchKernelGGL(kA8_jacobian<false>, dim3((unsigned)((alive + 7) / 8)), dim3(64), 0, s, c, SQ, cSlow, QB[cur], cB[cur], SQ, cSlow, cA[nxt]);
-            else
-                hipLaunchKernelGGL(kA_jacobian<false>, dim3((unsigned)((alive + 15) / 16)), dim3(64), 0, s, c, SQ, cSlow, QB[cur], cB[cur], SQ, cSlow, cA[nxt]);
+            hipLaunchKernelGGL(kA_jacobian<false>, dim3((unsigned)std::min<long long>((alive + 15) / 16, (long long)cus * 8)), dim3(64), 0, s, c, SQ, cSlow, QB[cur], cB[cur], SQ, cSlow, cA[nxt]);
             FSQ_HIP_CHECK(hipMemsetAsync(cSlow, 0, sizeof(int), s));
             nB += slow_pending;
             if (alive < nB) alive = nB;

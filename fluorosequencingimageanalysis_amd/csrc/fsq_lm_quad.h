@@ -21,9 +21,12 @@
 // ---- LDS layout (units: doubles, per quad; element e of quad q lives at lds[(e)*16 + q]) ----------
 enum {
     // used by the Jacobian round (first Q_KA_END doubles only)
-    Q_X = 0, Q_DIAG = 7, Q_QTF = 14, Q_WA3 = 21, Q_ACN = 28 /* acnorm by slot */, Q_RDIAG = 35 /* by logical position */,
-    Q_WA = 42 /* by logical position */, Q_TMP = 49 /* 7 */, Q_R = 56 /* 7 rows x 7 slots: R(i,k) = Q_R + i*7 + slot(k) */,
-    Q_FVEC = 105, Q_DATA = 130, Q_KA_END = 155,
+    Q_X = 0, Q_DIAG = 7, Q_TMP = 14 /* 7 */, Q_QTF = 21, Q_WA3 = 28, Q_ACN = 35 /* acnorm by slot */,
+    Q_RDIAG = 42 /* by logical position */, Q_WA = 49 /* by logical position */,
+    Q_R = 56 /* 7 rows x 7 slots: R(i,k) = Q_R + i*7 + slot(k) */, Q_FVEC = 105, Q_DATA = 130, Q_KA_END = 155,
+    // the Jacobian round stages the model evaluations of its pixel-split fdjac2 in the 84 doubles from Q_QTF to the end of
+    // Q_R, which are only written later (qrfac) - three 25-pixel columns at a time
+    Q_STAGE = 21,
     // additionally used by the single-launch persistent quad engine
     Q_SDIAG = 155, Q_XLM = 162, Q_WA1 = 169, Q_WA2 = 176, Q_WA4 = 183, Q_TMP2 = 208 /* 7 */, Q_TMP3 = 215 /* 7 */, Q_END = 222
 };

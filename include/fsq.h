@@ -269,10 +269,14 @@ int fsq_selftest_division(const double* d_num, const double* d_den, int64_t n, i
 /* fsq_selftest_rotation: qrsolv's 0.5 / sqrt(.25 + .25 t^2) (|t| <= 1) is evaluated by the cores of the compiler's
  * sqrt and division expansions (fsq_devmath.h); counts the d_t[i] for which that differs from the plain expression. */
 int fsq_selftest_rotation(const double* d_t, int64_t n, int64_t* mismatches, void* stream);
-/* fsq_selftest_exp: the Jacobian kernel's branch-free exp (fsq_exp_bf, and its two-half form) against the branching
- * restatement of glibc's exp (fsq_exp) - bit equality outside 512 <= |x| < 1024, where instead the range flag must
- * be raised (and only there). */
+/* fsq_selftest_exp: the fit kernels' branch-free exp (fsq_exp_bf) against the branching restatement of glibc's exp
+ * (fsq_exp) - bit equality for |x| < 512; everywhere else (NaN included) the range flag must be raised instead. */
 int fsq_selftest_exp(const double* d_x, int64_t n, int64_t* mismatches, void* stream);
+/* fsq_selftest_square: qrfac's norm down-dating needs libm's pow(t, 2.0) (mpfit.py:1816, a NumPy scalar ** 2); the
+ * Jacobian kernel takes t * t wherever that provably is the same number (fsq_square_is_pow2: t^2 further than pow's
+ * own error bound from a rounding boundary).  Counts the d_t[i] for which the predicate holds and pow(t, 2.0) != t * t
+ * (must be 0), and those for which it does not hold (*undecided; about 3 % of random arguments). */
+int fsq_selftest_square(const double* d_t, int64_t n, int64_t* mismatches, int64_t* undecided, void* stream);
 int64_t fsq_fit_last_slow_count(void);
 
 #ifdef __cplusplus

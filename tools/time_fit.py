@@ -27,14 +27,13 @@ if hasattr(L,'fsq_debug_phase_cycles'):
     print('inner passes per trip',v[8]/max(v[9],1),'trips',v[9])
 
 if hasattr(L,'fsq_debug_rphase'):
-    buf=(ctypes.c_ulonglong*16)(); L.fsq_debug_rphase(buf,1); v=list(buf)
-    names=['loop/idle','load','lmpar','step logic','trial eval','update logic','store']
-    tot=sum(v[:7])
-    for nm,c in zip(names,v[:7]): print('kB %-12s %6.2f%%'%(nm,100*c/max(tot,1)))
-
-    names=['loop/idle','load','J evals','diff+peg','qrfac','gnorm etc','handover']
-    tot=sum(v[8:15])
-    for nm,c in zip(names,v[8:15]): print('kA %-12s %6.2f%%'%(nm,100*c/max(tot,1)))
-    print('kA total / kB total cycles: %.2f'%(tot/max(sum(v[:7]),1)))
+    buf=(ctypes.c_ulonglong*32)(); L.fsq_debug_rphase(buf,1); v=list(buf)
+    kb=dict(zip(['loop/idle','load','lmpar run','step logic','trial eval','update logic','store','lmpar begin'],v[:8]))
+    tot=sum(kb.values())
+    for nm,c in kb.items(): print('kB %-12s %6.2f%%'%(nm,100*c/max(tot,1)))
+    ka=dict(zip(['loop/idle','load+stage','J evals','diff+peg','qrfac: norms','gnorm etc','handover','qr: pivot','qr: owner','qr: updates','qr: downdate','qr: tail'],v[16:28]))
+    tota=sum(ka.values())
+    for nm,c in ka.items(): print('kA %-12s %6.2f%%'%(nm,100*c/max(tota,1)))
+    print('kA total / kB total cycles: %.2f'%(tota/max(tot,1)))
     passes=float(r['niter'].sum())*3
-    print('kA ticks per wave-pass (16 fits): %.0f   kB ticks per wave-pass (64 fits): %.0f'%(tot/(passes/16), sum(v[:7])/(passes/64)))
+    print('kA ticks per wave-pass (16 fits): %.0f   kB ticks per wave-pass (64 fits): %.0f'%(tota/(passes/16), tot/(passes/64)))
