@@ -57,6 +57,13 @@ __device__ unsigned long long g_rphase[32];
 // Indexed by candidate: a compact 64-byte copy of the 25 ROI pixels (kinit), the model's 25 exponentials E at the current
 // point (written on acceptance, read by kA, which rebuilds fvec = data - (x0 + x1 E) from them), the final result, the ROI
 // statistics.
+// Counters of one ping/pong set of queues (8 ints): fits waiting in queue A, in the two lists of queue B and the two of queue C.
+// Queues B and C each hold TWO lists in one array, one growing from position 0 upwards and one from cap - 1 downwards:
+//   B lo / hi   input of the step round, binned by the number of Newton iterations lmpar took for this fit LAST time
+//               (<= 1 / more: the count is sticky per fit, oracle statistics in DESIGN.md) - a wave's lanes then mostly finish
+//               lmpar together instead of all waiting for the slowest
+//   C 1 / 3     fits parked in the middle of lmpar after 1 resp. 3 iterations; they are picked up by the NEXT round's launch
+enum { CNT_A = 0, CNT_BLO = 1, CNT_BHI = 2, CNT_C1 = 3, CNT_C3 = 4, CNT_SET = 8 };
 enum { Q_EPS = Q_WA3 };           // kA, during qrfac: relative error bounds of the tracked column norms (by logical position)
 enum { A_IDX = 0, A_X = 1, A_DIAG = 8, A_LLIM1 = 15, A_FNORM = 16, A_PAR = 17, A_DELTA = 18, A_XNORM = 19, A_ITER = 20,
        A_LEN = 21,
@@ -233,7 +240,7 @@ __global__ void __launch_bounds__(256) kinit(Ctx c, BatchArgs b, double* __restr
         q[(A_X + k) * cap] = t;
         q[(A_DIAG + k) * cap] = 0.;
     }
-    q[A_IDX * cap] = pack2((int)((unsigned)slot | ((unsigned)b.ticket << c.tshift)), 0);
+    q[A_IDX * cap] = pack2((int)((unsigned)slot | ((unsigned)b.ticket << c.tshift)), 0);       // (second word: lmpar history, none yet)
     q[A_LLIM1 * cap] = llim1; q[A_FNORM * cap] = 0.; q[A_PAR * cap] = 0.; q[A_DELTA * cap] = 0.; q[A_XNORM * cap] = 0.;
     q[A_ITER * cap] = pack2(1, 0);                                         // niter = 1, nfev = 0  (nfev == 0 <=> fresh)
     c.stat[slot].vmax = mx; c.stat[slot].vmean = vmean;
@@ -265,70 +272,118 @@ FSQ_DEV double ka_gauss(double nu, double nv, const FsqDivisor& k4, const FsqDiv
 }
 
 // ---------------------------------------------------------------------------------------------------
-// kA: Jacobian round.  block = 64 threads = 16 quads, grid-stride over list A.
+// kA: Jacobian round.  block = 64 threads; L lanes per fit (a "group"), 64 / L fits per wave; one trip per block.
+//   L = 4: lane c of a group owns columns c and c + 4 (two 25-row columns in registers, 256 VGPRs, 2 waves per SIMD)
+//   L = 8: lane c owns column c alone (128 VGPRs and half the LDS per wave: 4 waves per SIMD)
+// Slot s of the 8 columns (7 Jacobian columns + the residual vector f, slot 7) lives in lane s % L, register set s / L.
+// A lone wave issues one fp64 instruction every 5 (independent) to 9 (dependent) cycles whatever else is free
+// (tools/ubench/fma_latency.hip), and this round is one long dependent chain: its throughput is waves in flight per
+// wave latency, not instruction count - hence the 8-lane form, which trades ~1.4x the instructions per fit for twice the
+// waves.
 // FAST = true: divisions by a shared divisor go through fsq_div_by (fsq_devmath.h) and every operand range that
-// makes it bit-identical to `/` is checked on the way; a quad that leaves those ranges writes nothing and appends
-// a copy of its queue-A record to the slow queue SQ, which the FAST = false build (plain divisions, same code) works
-// off when the host next looks (fits are independent, so a fit may fall a few rounds behind).
+// makes it bit-identical to `/` is checked on the way; a group that leaves those ranges writes nothing and appends
+// a copy of its queue-A record to the slow queue SQ, which the FAST = false build (plain divisions, libm pow, same code)
+// works off when the host next looks (fits are independent, so a fit may fall a few rounds behind).
 // The FAST build also zeroes the queue counters of the next round (nobody reads or appends to them during kA).
-// One trip per block (the FAST = false build strides over the slow queue with a small grid).  A third of a lone trip used
-// to be memory round trips - record, then pixels / E by the slot the record names, then five scalars fetched late, then
-// the queue-B reservation at the very end - so: the whole record is fetched up front (lane c4 of the quad takes fields c4,
-// c4 + 4, ...; the scalars wait in LDS), the reservation is made at the top (a quad that turns out not to need its slot
-// leaves a DEAD record, tag -1, which the step round skips), and the parameter-only part of fdjac2 (steps, sin / cos,
-// divisors) runs while the pixels and E are on their way.
-template <bool FAST>
-__global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __restrict__ QA, const int* __restrict__ cntA_p,
-                                                     double* __restrict__ QB, int* __restrict__ cntB_p,
-                                                     double* __restrict__ SQ, int* __restrict__ slow_cnt,
-                                                     int* __restrict__ next_counters)
+// The FAST = false build strides over the slow queue with a small grid.  Memory round trips are kept off the critical
+// path: the whole record is fetched up front (lane c takes fields c, c + L, ...; the scalars wait in LDS), the queue-B
+// slot is reserved at the top (a group that turns out not to need it leaves a DEAD record, tag -1, which the step round
+// skips), and the parameter-only part of fdjac2 runs while the pixels and E (fetched by the slot the record names) are
+// on their way.
+#pragma push_macro("QL")
+#undef QL
+#define QL(off, e) lds[((off) + (e)) * G + grp]
+template <int G>
+FSQ_DEV double kag_dot7(const double* lds, int grp, int off)
 {
-    __shared__ double lds[Q_KA_END * 16];
-    const int lane = threadIdx.x, quad = lane >> 2, c4 = lane & 3, qbase = lane & ~3;
+    double d = 0.0;
+#pragma unroll
+    for (int i = 0; i < 7; i++) { double v = QL(off, i); d = fsq_fma(v, v, d); }
+    return d;
+}
+template <int G>
+FSQ_DEV double kag_dot25(const double* lds, int grp, int off)
+{
+    double S[4];
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        double a = QL(off, l), b = QL(off, 4 + l), c = QL(off, 8 + l), e = QL(off, 12 + l);
+        S[l] = ((a * a + b * b) + c * c) + e * e;
+    }
+    double d = (S[0] + S[2]) + (S[1] + S[3]);
+#pragma unroll
+    for (int i = 16; i < 25; i++) { double v = QL(off, i); d = fsq_fma(v, v, d); }
+    return d;
+}
+
+// KA_ROWS: a scheduling fence every few rows of the unrolled 25-row loops (with 128 registers per lane the scheduler must not
+// pull all 25 LDS reads of a loop to its top); KA_PIN: keeps a running exponent minimum a chain (left to itself the
+// optimiser turns it into one tree at the end of the kernel and keeps every numerator alive for it)
+#define KA_ROWS(i) do { if (L == 8 && ((i) % 5) == 4) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define KA_PIN(v) do { if (FAST) asm volatile("" : "+v"(v)); } while (0)
+template <bool FAST, int L>
+__global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const double* __restrict__ QA, const int* __restrict__ cntA_p,
+                                                                    double* __restrict__ QB, int* __restrict__ cnt_cur,
+                                                                    double* __restrict__ SQ, int* __restrict__ slow_cnt,
+                                                                    int* __restrict__ next_counters)
+{
+    constexpr int G = 64 / L;                   // fits per wave
+    constexpr int NC = 8 / L;                   // columns per lane
+    constexpr int MPX = (FSQ_NPIX + L - 1) / L; // pixels per lane when a 25-pixel job is split over the group
+    constexpr int MREC = (A_LEN + L - 1) / L;   // record fields per lane
+    __shared__ double lds[Q_KA_END * G];
+    const int lane = threadIdx.x, grp = lane / L, cl = lane % L, gbase = lane - cl;
     const int n7 = FSQ_NP;
     if (c.wave_prio) __builtin_amdgcn_s_setprio(3);
     const int cntA = FAST ? *cntA_p : *slow_cnt;
     if (!FAST && blockIdx.x == 0 && threadIdx.x == 0 && cntA > 0) atomicAdd(c.slow_total, cntA);
-    if (FAST && blockIdx.x == 0 && threadIdx.x < 4) next_counters[threadIdx.x] = 0;
-    double ca[FSQ_NPIX], cb[FSQ_NPIX];
+    if (FAST && blockIdx.x == 0 && threadIdx.x < CNT_SET) next_counters[threadIdx.x] = 0;
+    double col[NC][FSQ_NPIX];
     RPH_DECL
     const long long cap = c.cap;
-    const int stride = gridDim.x * 16;
-    int base = blockIdx.x * 16;
+    const int stride = gridDim.x * G;
+    int base = blockIdx.x * G;
     if (base >= cntA) return;
     do {
         RPH_MARK(0)
-        const bool active = (base + quad) < cntA;
-        const NtQ qa = ntq(QA + (active ? base + quad : 0));
-        double rec[6];                      // fields c4, c4 + 4, ... of the 21-field queue-A record
+        const bool active = (base + grp) < cntA;
+        const NtQ qa = ntq(QA + (active ? base + grp : 0));
+        double rec[MREC];                   // fields cl, cl + L, ... of the 21-field queue-A record
 #pragma unroll
-        for (int m = 0; m < 6; m++) { const int f = c4 + 4 * m; rec[m] = (active && f < A_LEN) ? (double)qa[f * cap] : 0.0; }
-        int at = wave_reserve(cntB_p, active && c4 == 0);       // this quad's queue-B slot (see above)
-        at = __shfl(at, qbase);
+        for (int m = 0; m < MREC; m++) { const int f = cl + L * m; rec[m] = (active && f < A_LEN) ? (double)qa[f * cap] : 0.0; }
         bool hz = false, qhz = false;     // FAST: some operand left the range in which fsq_div_by == `/`
         int emin = 0;                     // FAST: smallest exponent among the tracked numerators
-        int tag, niter, nfev, dummy_;
-        unpack2(quad_bcast(rec[0], qbase), &tag, &dummy_);      // field 0 = A_IDX, field 20 = A_ITER: both in lane 0's share
-        unpack2(quad_bcast(rec[5], qbase), &niter, &nfev);
+        int tag, niter, nfev, hist;
+        unpack2(__shfl(rec[A_IDX / L], gbase + A_IDX % L), &tag, &hist);
+        unpack2(__shfl(rec[A_ITER / L], gbase + A_ITER % L), &niter, &nfev);
+        // this fit's queue-B slot (see above), in the list its lmpar history selects
+        const bool b_hi = hist > 1;
+        const int at_lo = wave_reserve(cnt_cur + CNT_BLO, active && cl == 0 && !b_hi);
+        const int at_hi = wave_reserve(cnt_cur + CNT_BHI, active && cl == 0 && b_hi);
+        const long long at = __shfl(b_hi ? (int)(cap - 1) - at_hi : at_lo, gbase);
         const int idx = tag_slot(c, tag);
         const bool fresh = active && (nfev == 0);
         double llim1 = 0., fnorm = 0., xnorm = 0., delta = 0., par_in = 0.;
         unsigned ipvt = 0x76543210u;
         int status = 0;
         double gnorm = 0.;
-        uint4 roi = make_uint4(0u, 0u, 0u, 0u);
-        double ev[7];
+        uint4 roi = make_uint4(0u, 0u, 0u, 0u);     // this lane's 32 / L pixels of the compact ROI copy
+        double ev[MPX];
 #pragma unroll
-        for (int m = 0; m < 7; m++) ev[m] = 0.0;
+        for (int m = 0; m < MPX; m++) ev[m] = 0.0;
         if (active) {                       // pixels and E by pool slot: on their way while the parameters are worked on
-            roi = nt_ld4(c.roi + (size_t)idx * 32 + c4 * 8);
+            if (L == 4) roi = nt_ld4(c.roi + (size_t)idx * 32 + cl * 8);
+            else {
+                const unsigned long long w8 = fsq_bits(nt_ld((const double*)(c.roi + (size_t)idx * 32 + cl * 4)));
+                roi.x = (unsigned)w8; roi.y = (unsigned)(w8 >> 32);
+            }
             if (!fresh) {
 #pragma unroll
-                for (int m = 0; m < 7; m++) { const int k = c4 + 4 * m; if (k < FSQ_NPIX) ev[m] = nt_ld(c.fvec + (size_t)idx * FSQ_NPIX + k); }
+                for (int m = 0; m < MPX; m++) { const int k = cl + L * m; if (k < FSQ_NPIX) ev[m] = nt_ld(c.fvec + (size_t)idx * FSQ_NPIX + k); }
             }
 #pragma unroll
-            for (int m = 0; m < 6; m++) {   // fields 1..19 -> LDS slots 0..18: x | diag | llim1 fnorm par delta xnorm (Q_X, Q_DIAG, Q_TMP[0..4])
-                const int f = c4 + 4 * m;
+            for (int m = 0; m < MREC; m++) {    // fields 1..19 -> LDS slots 0..18: x | diag | llim1 fnorm par delta xnorm (Q_X, Q_DIAG, Q_TMP[0..4])
+                const int f = cl + L * m;
                 if (f >= 1 && f <= 19) QL(Q_X, f - 1) = rec[m];
             }
         }
@@ -340,8 +395,8 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
             // and p1 and f(x) itself need no new exp: they follow from E at the current point, which is what the step
             // round leaves in c.fvec (fvec = data - (x0 + x1 * E) is rebuilt from it with the operations that produced it).
             // The five columns that do need the model (c2, c3, sigma4, sigma5, theta) are evaluated split by PIXEL over the
-            // quad - lane c4 takes pixels c4, c4 + 4, ... for every column - and handed to the lanes that own the columns
-            // through the staging slots: 35 pixel evaluations per lane in lock step instead of 50.
+            // group - lane cl takes pixels cl, cl + L, ... for every column - and handed to the lanes that own the columns
+            // through the staging slots.
             double xx[FSQ_NP], hh[FSQ_NP];
 #pragma unroll
             for (int k = 0; k < FSQ_NP; k++) {
@@ -361,24 +416,24 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
             if (FAST)       // |numerator| <= |p2| + |p3| + 8: bounded once the centre is
                 hz = hz || !fsq_divisor_in_range(xx[4]) || !fsq_divisor_in_range(xx[5]) || !(__builtin_fabs(xx[2]) <= 0x1p100) ||
                      !(__builtin_fabs(xx[3]) <= 0x1p100);
-            {   // the pixels and E have arrived by now: lane c4 of the quad converts pixels 8 c4 .. 8 c4 + 7 of the ROI copy
+            {   // the pixels and E have arrived by now: lane cl converts its 32 / L pixels of the ROI copy
                 const unsigned w[4] = {roi.x, roi.y, roi.z, roi.w};
 #pragma unroll
-                for (int t = 0; t < 8; t++) {
-                    const int k = c4 * 8 + t;
+                for (int t = 0; t < 32 / L; t++) {
+                    const int k = cl * (32 / L) + t;
                     if (k < FSQ_NPIX) QL(Q_DATA, k) = (double)((w[t >> 1] >> (16 * (t & 1))) & 0xffffu);
                 }
                 if (!fresh) {
 #pragma unroll
-                    for (int m = 0; m < 7; m++) { const int k = c4 + 4 * m; if (k < FSQ_NPIX) QL(Q_FVEC, k) = ev[m]; }
+                    for (int m = 0; m < MPX; m++) { const int k = cl + L * m; if (k < FSQ_NPIX) QL(Q_FVEC, k) = ev[m]; }
                 }
             }
             WAVE_SYNC();
             if (__ballot(fresh)) {          // mpfit's first function call (mpfit.py:999): E at x0 (whole batches are fresh together)
                 if (fresh) {
 #pragma unroll 1
-                    for (int m = 0; m < 7; m++) {
-                        const int i = c4 + 4 * m;
+                    for (int m = 0; m < MPX; m++) {
+                        const int i = cl + L * m;
                         if (i < FSQ_NPIX) {
                             const int xi = i / 5;
                             const double x = (double)xi, y = (double)(i - 5 * xi);
@@ -398,8 +453,8 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                 const double rcx3 = x3p * cs - xx[2] * sn, rcy3 = x3p * sn + xx[2] * cs;
                 if (FAST) hz = hz || !(__builtin_fabs(x2p) <= 0x1p100) || !(__builtin_fabs(x3p) <= 0x1p100);
 #pragma unroll 1
-                for (int m = 0; m < 7; m++) {
-                    const int i = c4 + 4 * m;
+                for (int m = 0; m < MPX; m++) {
+                    const int i = cl + L * m;
                     if (i < FSQ_NPIX) {
                         const int xi = i / 5;
                         const double x = (double)xi, y = (double)(i - 5 * xi);
@@ -411,26 +466,26 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                         QL(Q_STAGE + 25, i) = d - (xx[0] + xx[1] * E3);
                     }
                 }
-                const double p0 = (c4 == 0) ? xx[0] + hh[0] : xx[0], p1 = (c4 == 1) ? xx[1] + hh[1] : xx[1];
+                const double p0 = (cl == 0) ? xx[0] + hh[0] : xx[0], p1 = (cl == 1) ? xx[1] + hh[1] : xx[1];
 #pragma unroll
-                for (int i = 0; i < FSQ_NPIX; i++) ca[i] = QL(Q_DATA, i) - (p0 + p1 * QL(Q_FVEC, i));
+                for (int i = 0; i < FSQ_NPIX; i++) { col[0][i] = QL(Q_DATA, i) - (p0 + p1 * QL(Q_FVEC, i)); KA_ROWS(i); }    // slots 0, 1 (lanes 0, 1)
                 WAVE_SYNC();
-                if (c4 >= 2) {
+                if (cl == 2 || cl == 3) {                                                           // slots 2, 3
 #pragma unroll
-                    for (int i = 0; i < FSQ_NPIX; i++) ca[i] = QL(Q_STAGE + 25 * (c4 - 2), i);
+                    for (int i = 0; i < FSQ_NPIX; i++) { col[0][i] = QL(Q_STAGE + 25 * (cl - 2), i); KA_ROWS(i); }
                 }
                 // every lane has read E: fvec = f(x) takes its place (each lane its own pixels)
-                double fvm[7];
+                double fvm[MPX];
 #pragma unroll
-                for (int m = 0; m < 7; m++) {
-                    const int i = c4 + 4 * m;
-                    fvm[m] = (m < 6 || i < FSQ_NPIX) ? QL(Q_DATA, i) - (xx[0] + xx[1] * QL(Q_FVEC, i)) : 0.0;
+                for (int m = 0; m < MPX; m++) {
+                    const int i = cl + L * m;
+                    fvm[m] = (i < FSQ_NPIX) ? QL(Q_DATA, i) - (xx[0] + xx[1] * QL(Q_FVEC, i)) : 0.0;
                 }
                 WAVE_SYNC();
 #pragma unroll
-                for (int m = 0; m < 7; m++) {
-                    const int i = c4 + 4 * m;
-                    if (m < 6 || i < FSQ_NPIX) QL(Q_FVEC, i) = fvm[m];
+                for (int m = 0; m < MPX; m++) {
+                    const int i = cl + L * m;
+                    if (i < FSQ_NPIX) QL(Q_FVEC, i) = fvm[m];
                 }
             }
             {   // phase B: the columns of sigma4, sigma5 (one new quotient each) and theta (a new rotation), by pixel
@@ -441,8 +496,8 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                 const double rcxt = xx[3] * cst - xx[2] * snt, rcyt = xx[3] * snt + xx[2] * cst;
                 if (FAST) hz = hz || !fsq_divisor_in_range(x4p) || !fsq_divisor_in_range(x5p);
 #pragma unroll 1
-                for (int m = 0; m < 7; m++) {
-                    const int i = c4 + 4 * m;
+                for (int m = 0; m < MPX; m++) {
+                    const int i = cl + L * m;
                     if (i < FSQ_NPIX) {
                         const int xi = i / 5;
                         const double x = (double)xi, y = (double)(i - 5 * xi);
@@ -463,62 +518,74 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                     }
                 }
                 WAVE_SYNC();
+                // slots 4, 5, 6 and 7 (= fvec): lanes 0..3 second register set (L = 4), lanes 4..7 (L = 8)
+                const int s47 = (L == 4) ? cl + 4 : cl;
+                if (s47 >= 4) {
 #pragma unroll
-                for (int i = 0; i < FSQ_NPIX; i++) cb[i] = QL((c4 < 3) ? Q_STAGE + 25 * c4 : Q_FVEC, i);
+                    for (int i = 0; i < FSQ_NPIX; i++) { col[NC - 1][i] = QL((s47 < 7) ? Q_STAGE + 25 * (s47 - 4) : Q_FVEC, i); KA_ROWS(i); }
+                }
             }
             if (FAST) hz = hz || bad;
-            const double hA = (c4 == 0) ? hh[0] : (c4 == 1) ? hh[1] : (c4 == 2) ? hh[2] : hh[3];
-            const double hB = (c4 == 0) ? hh[4] : (c4 == 1) ? hh[5] : (c4 == 2) ? hh[6] : 0.0;
+            double hcol[NC];
+#pragma unroll
+            for (int pass = 0; pass < NC; pass++) {
+                const int slot = cl + L * pass;
+                double h_ = 0.0;
+#pragma unroll
+                for (int k = 0; k < FSQ_NP; k++) h_ = (slot == k) ? hh[k] : h_;
+                hcol[pass] = h_;                  // 0 for slot 7: its quotient is not used
+            }
             RPH_MARK(2)
-            if (fresh && c4 == 0) QL(Q_TMP, 1) = fsq_sqrt(lds_dot25(lds, quad, Q_FVEC));     // fnorm of a fresh fit
+            if (fresh && cl == 0) QL(Q_TMP, 1) = fsq_sqrt(kag_dot25<G>(lds, grp, Q_FVEC));     // fnorm of a fresh fit
             nfev += 7;
             WAVE_SYNC();            // (the staging slots are free again: qrfac writes Q_ACN .. Q_R below)
-            bool pegA = false, pegB = false;
             {
-                double sA = 0.0, sB = 0.0;
-                const FsqDivisor kA_ = fsq_divisor(hA), kB_ = fsq_divisor(hB);     // hB = 0 in lane 3: quotient unused
-                if (FAST) {
-                    hz = hz || !fsq_divisor_in_range(hA) || !fsq_divisor_in_range(hB);
-                    // residuals are bounded by 2^16 + x0 + x1, so the numerators below stay under 2^102
-                    hz = hz || !(QL(Q_X, 0) <= 0x1p100) || !(QL(Q_X, 1) <= 0x1p100);
+                double ssum[NC];
+                FsqDivisor kh[NC];
+#pragma unroll
+                for (int pass = 0; pass < NC; pass++) {
+                    ssum[pass] = 0.0;
+                    kh[pass] = fsq_divisor(hcol[pass]);
+                    if (FAST) hz = hz || !fsq_divisor_in_range(hcol[pass]);
                 }
+                // residuals are bounded by 2^16 + x0 + x1, so the numerators below stay under 2^102
+                if (FAST) hz = hz || !(QL(Q_X, 0) <= 0x1p100) || !(QL(Q_X, 1) <= 0x1p100);
 #pragma unroll
                 for (int i = 0; i < FSQ_NPIX; i++) {
-                    double fv = QL(Q_FVEC, i);
-                    double nA_ = ca[i] - fv, nB_ = cb[i] - fv;
-                    if (FAST) { emin = min(emin, fsq_expo(nA_)); emin = min(emin, fsq_expo(nB_)); }
-                    ca[i] = fsq_div_sel<FAST>(nA_, kA_);
-                    double qB_ = fsq_div_sel<FAST>(nB_, kB_);
-                    cb[i] = (c4 < 3) ? qB_ : fv;
-                    sA += fv * ca[i];
-                    sB += fv * cb[i];
-                }
-                {   // pegged parameters (mpfit.py:1073-1091)
-                    const int slot = c4;
-                    const double xs = QL(Q_X, slot), llim1 = QL(Q_TMP, 0);
-                    bool lp = (xs == fsq_llim(slot, llim1)), up = fsq_qulim(slot) && (xs == fsq_ulim(slot));
-                    pegA = (lp && sA > 0) || (up && sA < 0);
-                }
-                if (c4 < 3) {
-                    const int slot = c4 + 4;
-                    const double xs = QL(Q_X, slot), llim1 = QL(Q_TMP, 0);
-                    bool lp = (xs == fsq_llim(slot, llim1)), up = (xs == fsq_ulim(slot));
-                    pegB = (lp && sB > 0) || (up && sB < 0);
+                    const double fv = QL(Q_FVEC, i);
+#pragma unroll
+                    for (int pass = 0; pass < NC; pass++) {
+                        const int slot = cl + L * pass;
+                        const double nn = col[pass][i] - fv;
+                        if (FAST) { emin = min(emin, fsq_expo(nn)); KA_PIN(emin); }
+                        const double qq = fsq_div_sel<FAST>(nn, kh[pass]);
+                        col[pass][i] = (slot < 7) ? qq : fv;
+                        ssum[pass] += fv * col[pass][i];
+                    }
+                    KA_ROWS(i);
                 }
 #pragma unroll
-                for (int i = 0; i < FSQ_NPIX; i++) {
-                    if (pegA) ca[i] = 0;
-                    if (pegB) cb[i] = 0;
+                for (int pass = 0; pass < NC; pass++) {     // pegged parameters (mpfit.py:1073-1091)
+                    const int slot = cl + L * pass;
+                    bool peg = false;
+                    if (slot < 7) {
+                        const double xs = QL(Q_X, slot), ll1 = QL(Q_TMP, 0);
+                        const bool lp = (xs == fsq_llim(slot, ll1)), up = fsq_qulim(slot) && (xs == fsq_ulim(slot));
+                        peg = (lp && ssum[pass] > 0) || (up && ssum[pass] < 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < FSQ_NPIX; i++)
+                        if (peg) col[pass][i] = 0;
                 }
             }
             RPH_MARK(3)
             // ---- qrfac with column pivoting (mpfit.py:1748-1822), Q^T f fused in as slot 7 ----------
-            {
-                double nA = fsq_sqrt(dot_regcol(ca, 25));
-                QL(Q_ACN, c4) = nA; QL(Q_RDIAG, c4) = nA; QL(Q_WA, c4) = nA; QL(Q_EPS, c4) = 0.;
-                if (c4 < 3) {
-                    double nB = fsq_sqrt(dot_regcol(cb, 25));
-                    QL(Q_ACN, c4 + 4) = nB; QL(Q_RDIAG, c4 + 4) = nB; QL(Q_WA, c4 + 4) = nB; QL(Q_EPS, c4 + 4) = 0.;
+#pragma unroll
+            for (int pass = 0; pass < NC; pass++) {
+                const int slot = cl + L * pass;
+                if (slot < 7) {
+                    const double nn = fsq_sqrt(dot_regcol(col[pass], 25));
+                    QL(Q_ACN, slot) = nn; QL(Q_RDIAG, slot) = nn; QL(Q_WA, slot) = nn; QL(Q_EPS, slot) = 0.;
                 }
             }
             WAVE_SYNC();
@@ -555,52 +622,64 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                 }
                 RPH_MARK(7)
                 const int lj = nib_get(ipvt, j);
-                const int owner = qbase + (lj & 3);
-                const bool useB = (lj >> 2) != 0;
-                // The lane that owns the pivot column turns it into the Householder vector and publishes it in LDS
-                // (the Q_DATA slots: the pixels are not needed again in this pass); the other lanes of the quad read
-                // it from there, so no lane keeps a third 25-row column in registers.
-                int emin_s = 0;                                     // FAST: lower bound of the scaled reflector's exponents
+                const int owner = gbase + (lj % L);
+                // The lane that owns the pivot column publishes it in LDS (the Q_DATA slots: the pixels are not needed again
+                // in this pass) together with its norm; the group then turns it into the Householder vector row-parallel
+                // (lane cl scales rows cl, cl + L, ...) and every lane reads the vector from there, so no lane keeps a third
+                // 25-row column in registers and the scaling is not one lane's work.  (Letting every lane take the norm from
+                // the published column instead - no select between the owner's register sets - was measured 2 % slower.)
                 bool brk = false;
                 if (lane == owner) {
                     double t[FSQ_NPIX];
 #pragma unroll
-                    for (int i = 0; i < FSQ_NPIX; i++) t[i] = useB ? cb[i] : ca[i];
+                    for (int i = 0; i < FSQ_NPIX; i++) t[i] = (NC == 2 && (lj / L) != 0) ? col[NC - 1][i] : col[0][i];
+#pragma unroll
+                    for (int i = 0; i < FSQ_NPIX; i++) { QL(Q_DATA, i) = t[i]; KA_ROWS(i); }
                     if (!broken) {
                         double ajnorm = fsq_sqrt(dot_regcol(t, len));
                         if (ajnorm == 0) brk = true;                // mpfit.py:1790 `break`
                         else {
                             if (t[0] < 0) ajnorm = -ajnorm;
-                            const FsqDivisor kn = fsq_divisor(ajnorm);
-                            if (FAST) {
-                                int er = 0;
-#pragma unroll
-                                for (int i = 0; i < FSQ_NPIX; i++) er = min(er, fsq_expo(t[i]));
-                                emin = min(emin, er);               // |t[i]| <= |ajnorm|: no upper check needed
-                                hz = hz || !fsq_divisor_in_range(ajnorm);
-                                emin_s = er - fsq_expo(ajnorm) - 1;
-                            }
-#pragma unroll
-                            for (int i = 0; i < FSQ_NPIX; i++) t[i] = fsq_div_sel<FAST>(t[i], kn);   // rows >= len are zeros
-                            t[0] = t[0] + 1;
                             QL(Q_TMP, 5) = -ajnorm;
+                            QL(Q_TMP, 6) = ajnorm;
                         }
                     }
-#pragma unroll
-                    for (int i = 0; i < FSQ_NPIX; i++) QL(Q_DATA, i) = t[i];
                 }
                 WAVE_SYNC();
                 broken = broken || (__shfl((int)brk, owner) != 0);
-                emin_s = __shfl(emin_s, owner);
+                int emin_s = 0;                                     // FAST: lower bound of the scaled reflector's exponents
+                if (!broken) {
+                    const double ajn = QL(Q_TMP, 6);
+                    const FsqDivisor kn = fsq_divisor(ajn);
+                    int er = 0;
+                    if (FAST) hz = hz || !fsq_divisor_in_range(ajn);
+#pragma unroll
+                    for (int m = 0; m < MPX; m++) {
+                        const int i = cl + L * m;
+                        if (i < FSQ_NPIX) {
+                            const double raw = QL(Q_DATA, i);       // rows >= len are zeros
+                            if (FAST) { er = min(er, fsq_expo(raw)); KA_PIN(er); }
+                            double q_ = fsq_div_sel<FAST>(raw, kn);
+                            if (i == 0) q_ = q_ + 1;
+                            QL(Q_DATA, i) = q_;
+                        }
+                    }
+                    if (FAST) {                                     // |raw| <= |ajnorm|: no upper check needed
+#pragma unroll
+                        for (int d = 1; d < L; d <<= 1) er = min(er, __shfl_xor(er, d));
+                        emin = min(emin, er);
+                        emin_s = er - fsq_expo(ajn) - 1;
+                    }
+                }
+                WAVE_SYNC();
                 RPH_MARK(8)
 #define REFL(i) QL(Q_DATA, i)
                 const double ajj0 = REFL(0);
                 const FsqDivisor kj = fsq_divisor(ajj0);
                 if (FAST) hz = hz || !fsq_divisor_in_range(ajj0);
 #pragma unroll
-                for (int pass = 0; pass < 2; pass++) {
-                    const int slot = c4 + 4 * pass;
-                    double* col = pass ? cb : ca;
+                for (int pass = 0; pass < NC; pass++) {
+                    const int slot = cl + L * pass;
                     const bool is_f = (slot == 7);
                     const int k = is_f ? 7 : nib_get(pos, slot);
                     const bool todo = is_f ? true : (!broken && k > j);
@@ -609,29 +688,29 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                         // rows >= len hold zeros (see the shift below): they add +0 to the sum and stay zero in
                         // the update, so neither loop needs a bound check and both are straight-line code
 #pragma unroll
-                        for (int i = 0; i < FSQ_NPIX; i++) s += col[i] * REFL(i);
+                        for (int i = 0; i < FSQ_NPIX; i++) { s += col[pass][i] * REFL(i); KA_ROWS(i); }
                         if (FAST) {     // numerators REFL(i) * s: |REFL(i)| < 4, exponent >= emin_s (or zero)
                             const int es = fsq_expo(s);
                             hz = hz || (emin_s + es - 2 < -FSQ_DIV_EN) || (es + 2 > FSQ_DIV_EN);
                         }
 #pragma unroll
-                        for (int i = 0; i < FSQ_NPIX; i++) col[i] = col[i] - fsq_div_sel<FAST>(REFL(i) * s, kj);
+                        for (int i = 0; i < FSQ_NPIX; i++) { col[pass][i] = col[pass][i] - fsq_div_sel<FAST>(REFL(i) * s, kj); KA_ROWS(i); }
                     }
-                    if (is_f) QL(Q_QTF, j) = col[0];
-                    else if (slot < 7 && nib_get(pos, slot) > j) QL(Q_R, j * 7 + slot) = col[0];
+                    if (is_f) QL(Q_QTF, j) = col[pass][0];
+                    else if (nib_get(pos, slot) > j) QL(Q_R, j * 7 + slot) = col[pass][0];
                 }
-                // Norm down-dating of the live columns (mpfit.py:1810-1820).  It is scalar work per column (a divide, a
-                // pow, a sqrt, a divide), and at step j only the 6 - j columns at positions > j are live, scattered over
-                // the 8 register slots of the quad: instead of running it slot by slot (2 passes per step whatever is
-                // live) the lanes take the live POSITIONS in order - lane c4 position j+1+c4, then j+5+c4 - reading the
-                // column's new leading element R(j, .) from LDS: 8 passes per factorization instead of 14.  The rare full
-                // recomputation of a norm needs the column itself, so that goes back to the lane that holds it.
+                // Norm down-dating of the live columns (mpfit.py:1810-1820).  It is scalar work per column, and at step j only
+                // the 6 - j columns at positions > j are live, scattered over the 8 slots of the group: the lanes take the live
+                // POSITIONS in order - lane cl position j + 1 + cl (then j + 1 + L + cl) - reading the column's new leading
+                // element R(j, .) from LDS.  The rare full recomputation of a norm needs the column itself, so that goes back
+                // to the lane that holds it.
                 WAVE_SYNC();
                 RPH_MARK(9)
-                unsigned long long redo[2] = {0ull, 0ull};
+                constexpr int NSUB = (L == 4) ? 2 : 1;
+                unsigned long long redo[NSUB];
 #pragma unroll
-                for (int sub = 0; sub < 2; sub++) {
-                    const int p = j + 1 + c4 + 4 * sub;
+                for (int sub = 0; sub < NSUB; sub++) {
+                    const int p = j + 1 + cl + L * sub;
                     bool need = false;
                     if (p < n7 && !broken && ajj0 != 0) {
                         double rk = QL(Q_RDIAG, p);
@@ -676,15 +755,17 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                     }
                     redo[sub] = __ballot(need);
                 }
-                if (redo[0] | redo[1]) {
+                unsigned long long any_redo = 0ull;
 #pragma unroll
-                    for (int pass = 0; pass < 2; pass++) {
-                        const int slot = c4 + 4 * pass;
-                        const double* col = pass ? cb : ca;
+                for (int sub = 0; sub < NSUB; sub++) any_redo |= redo[sub];
+                if (any_redo) {
+#pragma unroll
+                    for (int pass = 0; pass < NC; pass++) {
+                        const int slot = cl + L * pass;
                         const int k = (slot < 7) ? nib_get(pos, slot) : 0;
-                        const int idx = k - j - 1;
-                        if (slot < 7 && idx >= 0 && ((redo[idx >> 2] >> (qbase + (idx & 3))) & 1ull)) {
-                            const double rk = fsq_sqrt(dot_regcol_from1(col, len));
+                        const int ix = k - j - 1;
+                        if (slot < 7 && ix >= 0 && ((redo[(NSUB == 2) ? ix / L : 0] >> (gbase + ix % L)) & 1ull)) {
+                            const double rk = fsq_sqrt(dot_regcol_from1(col[pass], len));
                             QL(Q_WA, k) = rk;
                             QL(Q_RDIAG, k) = rk;
                             if (FAST) QL(Q_EPS, k) = 0.;            // an exact norm again
@@ -695,13 +776,17 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                 if (!broken) QL(Q_RDIAG, j) = QL(Q_TMP, 5);
                 QL(Q_R, j * 7 + lj) = QL(Q_RDIAG, j);               // fjac[j, lj] = rdiag[j] (mpfit.py:1123)
 #pragma unroll
-                for (int i = 0; i + 1 < FSQ_NPIX; i++) { ca[i] = ca[i + 1]; cb[i] = cb[i + 1]; }
-                ca[FSQ_NPIX - 1] = 0.0; cb[FSQ_NPIX - 1] = 0.0;
+                for (int pass = 0; pass < NC; pass++) {
+#pragma unroll
+                    for (int i = 0; i + 1 < FSQ_NPIX; i++) col[pass][i] = col[pass][i + 1];
+                    col[pass][FSQ_NPIX - 1] = 0.0;
+                }
                 WAVE_SYNC();
                 RPH_MARK(11)
             }
             RPH_MARK(4)
             // ---- first iteration scaling, gradient test (mpfit.py:1099-1160) -----------------------
+#define QRG(i, k) QL(Q_R, (i) * 7 + nib_get(ipvt, (k)))
             llim1 = QL(Q_TMP, 0); fnorm = QL(Q_TMP, 1); par_in = QL(Q_TMP, 2); delta = QL(Q_TMP, 3); xnorm = QL(Q_TMP, 4);
             if (niter == 1) {
 #pragma unroll
@@ -711,7 +796,7 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                     QL(Q_DIAG, k) = dg;
                     QL(Q_WA3, k) = dg * QL(Q_X, k);
                 }
-                xnorm = fsq_sqrt(lds_dot7(lds, quad, Q_WA3));
+                xnorm = fsq_sqrt(kag_dot7<G>(lds, grp, Q_WA3));
                 delta = 100. * xnorm;
                 if (delta == 0.) delta = 100.;
             }
@@ -721,7 +806,7 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                     double an = QL(Q_ACN, nib_get(ipvt, j));
                     if (an != 0) {
                         double sg = 0.0;
-                        for (int i = 0; i <= j; i++) sg += QR(i, j) * QL(Q_QTF, i);
+                        for (int i = 0; i <= j; i++) sg += QRG(i, j) * QL(Q_QTF, i);
                         sg = sg / fnorm;
                         gnorm = np_max2(gnorm, __builtin_fabs(sg / an));
                     }
@@ -735,13 +820,13 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
             RPH_MARK(5)
             // ---- finish it (gradient test) ... ---------------------------------------------------------------
             if (FAST) {
-                // one verdict per quad: any lane out of range sends the whole fit to the plain-division kernel
+                // one verdict per fit: any lane out of range sends the whole fit to the plain-division kernel
                 hz = hz || (emin < -FSQ_DIV_EN);
                 if (c.force_slow_mod > 0 && (idx % c.force_slow_mod) == 0) hz = true;
                 const unsigned long long m = __ballot(hz);
-                qhz = ((m >> qbase) & 0xfull) != 0;
+                qhz = ((m >> gbase) & ((1ull << L) - 1ull)) != 0;
             }
-            if (status != 0 && c4 == 0 && !qhz) {
+            if (status != 0 && cl == 0 && !qhz) {
                 FitOut o;
 #pragma unroll
                 for (int k = 0; k < FSQ_NP; k++) o.x[k] = QL(Q_X, k);
@@ -749,56 +834,65 @@ __global__ void __launch_bounds__(64, 2) kA_jacobian(Ctx c, const double* __rest
                 c.out[idx] = o;
             }
         }
-        wave_mark_done(c.done, active && status != 0 && c4 == 0 && !qhz, tag_ticket(c, tag));
+        wave_mark_done(c.done, active && status != 0 && cl == 0 && !qhz, tag_ticket(c, tag));
         // ---- ... or hand it over to the step round (the queue-B slot reserved at the top) --------------------------------
         {
             bool go = active && (status == 0);
             if (FAST) {
-                int sat = wave_reserve(slow_cnt, qhz && c4 == 0);
-                sat = __shfl(sat, qbase);
-                if (qhz) for (int f = c4; f < A_LEN; f += 4) nt_st(SQ + (size_t)sat + f * cap, qa[f * cap]);
+                int sat = wave_reserve(slow_cnt, qhz && cl == 0);
+                sat = __shfl(sat, gbase);
+                if (qhz) for (int f = cl; f < A_LEN; f += L) nt_st(SQ + (size_t)sat + f * cap, qa[f * cap]);
                 go = go && !qhz;
             }
             const NtQ qb = ntq(QB + at);
             if (go) {
-                for (int e = c4; e < 28; e += 4) {
+                for (int e = cl; e < 28; e += L) {
                     int i = 0, rem = e;
                     while (rem >= 7 - i) { rem -= 7 - i; i++; }
-                    qb[(B_R + e) * cap] = QR(i, i + rem);
+                    qb[(B_R + e) * cap] = QRG(i, i + rem);
                 }
-                for (int k = c4; k < FSQ_NP; k += 4) {
+                for (int k = cl; k < FSQ_NP; k += L) {
                     qb[(A_X + k) * cap] = QL(Q_X, k);
                     qb[(A_DIAG + k) * cap] = QL(Q_DIAG, k);
                     qb[(B_QTF + k) * cap] = QL(Q_QTF, k);
                     qb[(B_SDIAG + k) * cap] = 0.;
                 }
-                if (c4 == 0) {
-                    qb[A_IDX * cap] = pack2(tag, 0);
+                if (cl == 0) {
+                    qb[A_IDX * cap] = pack2(tag, hist);
                     qb[A_LLIM1 * cap] = llim1; qb[A_FNORM * cap] = fnorm; qb[A_PAR * cap] = par_in; qb[A_DELTA * cap] = delta;
                     qb[A_XNORM * cap] = xnorm; qb[A_ITER * cap] = pack2(niter, nfev);
                     qb[B_GNORM * cap] = gnorm; qb[B_IPVT * cap] = pack2((int)ipvt, 0);
                 }
-            } else if (active && c4 == 0) qb[A_IDX * cap] = pack2(-1, 0);        // terminated or sent to the slow queue: a dead slot
+            } else if (active && cl == 0) qb[A_IDX * cap] = pack2(-1, 0);        // terminated or sent to the slow queue: a dead slot
         }
         RPH_MARK(6)
         base += stride;
     } while (!FAST && base < cntA);
     RPH_FLUSH(16)
 }
+#undef QRG
+#undef REFL
+#undef KA_ROWS
+#undef KA_PIN
+#pragma pop_macro("QL")
 
 // ---------------------------------------------------------------------------------------------------
-// kB: step round.  One lane per fit, grid-stride over list B.
-// lmpar's Newton iteration on par takes 1 iteration for half of the fits and all 10 for a quarter of them; a wave
-// would always wait for its slowest lane.  RESUME = false therefore stops after FSQ_LMPAR_FIRST iterations and parks
-// the lanes that are not done in queue C (their R / sdiag / par state as it stands); RESUME = true picks those up,
-// finishes lmpar and runs the same step logic.  Lanes of a resumed wave nearly all need the full 10 iterations.
+// kB: step round.  One lane per fit, one 64-fit tile per block.
+// lmpar's Newton iteration on par takes 0 or 1 iterations for half of the fits, 3 for a fifth and all 10 for a quarter of them
+// - and whatever a fit needed last time it most likely needs again (0 -> 0: 90 %, 1 -> 1: 86 %, 3 -> 3: 75 %, 10 -> 10: 82 %).
+// A wave waits for its slowest lane, so the fits are kept apart by that history: queue B holds two lists (last count <= 1 / more),
+// whose tiles stop lmpar after 1 resp. 3 iterations and PARK the lanes that are not done (their R / sdiag / par state as it
+// stands) in queue C, again in two lists (parked after 1 / after 3 iterations); the next round's launch picks those up and
+// runs them to 3 resp. to the end.  One launch per round works off all four lists.
+#ifndef FSQ_KA_LANES_DEFAULT
+#define FSQ_KA_LANES_DEFAULT 4
+#endif
 #ifndef FSQ_LMPAR_FIRST
-#define FSQ_LMPAR_FIRST 3
+#define FSQ_LMPAR_FIRST 5
 #endif
-#ifndef FSQ_KB_LOOP
-#define FSQ_KB_LOOP 0
+#ifndef FSQ_LMPAR_LO
+#define FSQ_LMPAR_LO 1
 #endif
-static constexpr bool KB_LOOP = FSQ_KB_LOOP != 0;
 #ifndef FSQ_KB_WAVES
 #define FSQ_KB_WAVES 2
 #endif
@@ -847,24 +941,36 @@ FSQ_DEV bool kb_trial_gauss(const double* p, double* myscr)
 
 FSQ_DEV double kb_late_load(const NtRef r) { asm volatile("" ::: "memory"); return (double)r; }
 
-template <bool ALIASED, bool RESUME>
-__global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double* __restrict__ QB, const int* __restrict__ cntB_p,
-                                                  double* __restrict__ QA_next, int* __restrict__ cntA_next,
-                                                  double* __restrict__ QB_next, int* __restrict__ cntB_next,
-                                                  double* __restrict__ QC, int* __restrict__ cntC, int lm_first)
+struct KbLimits { int lim[4]; };        // lmpar iteration limits of the four kinds of tiles: B lo, B hi, C 1, C 3
+template <bool ALIASED>
+__global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double* __restrict__ QB, const double* __restrict__ QC,
+                                                  const int* __restrict__ cnt_cur,
+                                                  double* __restrict__ QA_next, double* __restrict__ QB_next, double* __restrict__ QC_next,
+                                                  int* __restrict__ cnt_next, KbLimits lims)
 {
     __shared__ double scr[32 * 64];
     if (c.wave_prio) __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x;
-    const int cntB = *cntB_p;
+    const long long cap = c.cap;
     double* myscr = scr + lane;
     RPH_DECL
-    for (int base = blockIdx.x * 64; base < cntB; base += gridDim.x * 64) {
+    {
+        // One launch works off all four input lists, one 64-fit tile per block, the long-running kinds first: fits parked after
+        // 3 iterations (they run up to 7 more), B hi (3 iterations, then parked), fits parked after 1 iteration, B lo.
+        int b = blockIdx.x, seg, cnt;
+        const int n_lo = cnt_cur[CNT_BLO], n_hi = cnt_cur[CNT_BHI], n_c1 = cnt_cur[CNT_C1], n_c3 = cnt_cur[CNT_C3];
+        if (b < (n_c3 + 63) / 64) { seg = 3; cnt = n_c3; }
+        else if ((b -= (n_c3 + 63) / 64) < (n_hi + 63) / 64) { seg = 1; cnt = n_hi; }
+        else if ((b -= (n_hi + 63) / 64) < (n_c1 + 63) / 64) { seg = 2; cnt = n_c1; }
+        else if ((b -= (n_c1 + 63) / 64) < (n_lo + 63) / 64) { seg = 0; cnt = n_lo; }
+        else return;
+        const bool resume = seg >= 2;               // (wave-uniform)
+        const int lm_limit = lims.lim[seg];
+        const int base = b * 64;
         RPH_MARK(0)
-        bool live = (base + lane) < cntB;
-        const int slot_in = live ? (base + lane) : 0;
-        const long long cap = c.cap;
-        const NtQ qb = ntq(QB + slot_in);
+        bool live = (base + lane) < cnt;
+        const int p_in = live ? (base + lane) : base;
+        const NtQ qb = ntq((resume ? QC : QB) + ((seg & 1) ? cap - 1 - p_in : p_in));
         int tag, dummy, niter, nfev, ipvt_i;
         unpack2(qb[A_IDX * cap], &tag, &dummy);
         if (tag == -1) { live = false; tag = 0; }        // a slot the Jacobian round reserved and did not need (loads below stay in bounds)
@@ -893,25 +999,28 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
         for (int j = 0; j < FSQ_NP; j++) q.dgp[j] = myscr[nib_get(ipvt, j) * 64];
 
         RPH_MARK(1)
+        int lm_hist = 0;                        // Newton iterations this lmpar call took in all: the fit's history for its next record
         {
             QuadLmparSt st;
-            if (!RESUME) {
-                quadlm_lmpar_begin<ALIASED, 64>(q, myscr, ipvt, delta, par, st);
-                RPH_MARK(7)
-                quadlm_lmpar_run<ALIASED, 64>(q, myscr, ipvt, delta, st, lm_first);
-            } else {
+            if (!resume) quadlm_lmpar_begin<ALIASED, 64>(q, myscr, ipvt, delta, par, st);
+            else {
                 int it, dm;
                 unpack2(qb[C_LMIT * cap], &it, &dm);
                 st.par = par; st.parl = qb[C_PARL * cap]; st.paru = qb[C_PARU * cap]; st.fp = qb[C_FP * cap];
                 st.iter = it; st.done = false;
-                quadlm_lmpar_run<ALIASED, 64>(q, myscr, ipvt, delta, st, 10);
             }
+            RPH_MARK(7)
+            quadlm_lmpar_run<ALIASED, 64>(q, myscr, ipvt, delta, st, lm_limit);
             par = st.par;
-            if (!RESUME) {
+            lm_hist = st.iter;
+            {
+                // unfinished: park the fit (R / sdiag / par state as they stand) for the next round's launch
                 const bool park = live && !st.done;
-                const int atC = wave_reserve(cntC, park);
+                const bool to_c1 = (st.iter < lims.lim[2]);            // (C 1 tiles run to lim[2], C 3 tiles to the end: always progress)
+                const int at1 = wave_reserve(cnt_next + CNT_C1, park && to_c1);
+                const int at3 = wave_reserve(cnt_next + CNT_C3, park && !to_c1);
                 if (park) {
-                    const NtQ qn = ntq(QC + atC);
+                    const NtQ qn = ntq(QC_next + (to_c1 ? (long long)at1 : cap - 1 - at3));
                     qn[A_IDX * cap] = pack2(tag, 0);
 #pragma unroll
                     for (int k = 0; k < FSQ_NP; k++) {
@@ -1104,11 +1213,13 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
         {
             // accepted -> a new Jacobian (queue A); rejected -> another pass with the same, mutated R (queue B)
             const bool toA = live && status == 0 && accepted, toB = live && status == 0 && !accepted;
-            const int atA = wave_reserve(cntA_next, toA);
-            const int atB = wave_reserve(cntB_next, toB);
+            const bool hi = lm_hist > 1;
+            const int atA = wave_reserve(cnt_next + CNT_A, toA);
+            const int atBl = wave_reserve(cnt_next + CNT_BLO, toB && !hi);
+            const int atBh = wave_reserve(cnt_next + CNT_BHI, toB && hi);
             if (toA || toB) {
-                const NtQ qn = ntq(toA ? (QA_next + atA) : (QB_next + atB));
-                qn[A_IDX * cap] = pack2(tag, 0);
+                const NtQ qn = ntq(toA ? (QA_next + atA) : (QB_next + (hi ? cap - 1 - atBh : (long long)atBl)));
+                qn[A_IDX * cap] = pack2(tag, lm_hist);
 #pragma unroll
                 for (int k = 0; k < FSQ_NP; k++) { qn[(A_X + k) * cap] = xq[k]; qn[(A_DIAG + k) * cap] = q.dg[k]; }
                 qn[A_LLIM1 * cap] = llim1; qn[A_FNORM * cap] = fnorm; qn[A_PAR * cap] = par; qn[A_DELTA * cap] = delta;
@@ -1126,7 +1237,6 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
             }
         }
         RPH_MARK(6)
-        if (!KB_LOOP) break;                    // one trip per block (see fsq_launch_fit_rounds)
     }
     RPH_FLUSH(0)
 }
@@ -1316,10 +1426,11 @@ static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 // FsqFitQueue (include/fsq.h) keeps an engine alive across batches, so that the long latency-bound tail of one batch
 // (a fit may need 200 sequential iterations) rides along in the full launches of the batches submitted after it.
 namespace {
-enum { CTL_SLOW_TOTAL = 8, CTL_SLOW_CNT = 9, CTL_DONE = 16, CTL_INTS = CTL_DONE + FSQ_MAX_TICKETS };
+enum { CTL_SLOW_TOTAL = 2 * CNT_SET, CTL_SLOW_CNT = 2 * CNT_SET + 1, CTL_DONE = 2 * CNT_SET + 8, CTL_INTS = CTL_DONE + FSQ_MAX_TICKETS };
 
 struct RoundsCfg {
-    int trips = 1, lm_first = FSQ_LMPAR_FIRST, sync_mask = 3, force_slow_mod = 0, force_redo = 0, no_wave_prio = 0, trace = 0;
+    int trips = 1, lm_first = FSQ_LMPAR_FIRST, lm_lo = FSQ_LMPAR_LO, sync_mask = 3, force_slow_mod = 0, force_redo = 0, no_wave_prio = 0, trace = 0;
+    int ka_lanes = FSQ_KA_LANES_DEFAULT;               // lanes per fit in the Jacobian round (4 or 8)
     int max_rounds = 0, ka_lds_pad = 0, kb_lds_pad = 0;      // (debug: extra dynamic LDS per block = fewer waves per CU)
     long long two_pass_min = 524288, hiprio_below = 200000;
 };
@@ -1331,12 +1442,14 @@ RoundsCfg read_cfg()
     if ((e = getenv("FSQ_DEBUG_FORCE_NORM_RECOMPUTE")) != nullptr) g.force_redo = atoi(e) ? 1 : 0;
     if ((e = getenv("FSQ_TRIPS_PER_BLOCK")) != nullptr) g.trips = atoi(e);
     if ((e = getenv("FSQ_LMPAR_FIRST_ITERS")) != nullptr && atoi(e) >= 1 && atoi(e) <= 10) g.lm_first = atoi(e);
+    if ((e = getenv("FSQ_LMPAR_LO_ITERS")) != nullptr && atoi(e) >= 1 && atoi(e) <= 10) g.lm_lo = atoi(e);
     if ((e = getenv("FSQ_TWO_PASS_MIN")) != nullptr) g.two_pass_min = atoll(e);
     if ((e = getenv("FSQ_HIPRIO_BELOW")) != nullptr) g.hiprio_below = atoll(e);
     if ((e = getenv("FSQ_SYNC_EVERY")) != nullptr && atoi(e) >= 1) g.sync_mask = atoi(e) - 1;     // power of two
     if (getenv("FSQ_NO_WAVE_PRIO")) g.no_wave_prio = 1;
     if (getenv("FSQ_DEBUG_TRACE")) g.trace = 1;
     if ((e = getenv("FSQ_DEBUG_MAX_ROUNDS")) != nullptr) g.max_rounds = atoi(e);
+    if ((e = getenv("FSQ_KA_LANES")) != nullptr && (atoi(e) == 4 || atoi(e) == 8)) g.ka_lanes = atoi(e);
     if ((e = getenv("FSQ_DEBUG_KA_LDS_PAD")) != nullptr) g.ka_lds_pad = atoi(e);
     if ((e = getenv("FSQ_DEBUG_KB_LDS_PAD")) != nullptr) g.kb_lds_pad = atoi(e);
     return g;
@@ -1380,7 +1493,7 @@ size_t layout_bytes(size_t pool, size_t qcap)
 {
     size_t b = 4096;
     b += al256(pool * 64) + al256(pool * FSQ_NPIX * 8) + al256(pool * sizeof(FitOut)) + al256(pool * sizeof(FitStat));
-    b += 2 * al256(qcap * A_LEN * 8) + 2 * al256(qcap * B_LEN * 8) + al256(qcap * C_LEN * 8) + al256(qcap * A_LEN * 8);
+    b += 2 * al256(qcap * A_LEN * 8) + 2 * al256(qcap * B_LEN * 8) + 2 * al256(qcap * C_LEN * 8) + al256(qcap * A_LEN * 8);
     return b;
 }
 }  // namespace
@@ -1389,13 +1502,13 @@ struct FsqFitQueue {
     Ctx c;
     size_t pool = 0, qcap = 0;
     int* ctl = nullptr;
-    double *QA[2], *QB[2], *QC = nullptr, *SQ = nullptr;
-    int *cA[2], *cB[2], *cC[2], *cSlow = nullptr;
+    double *QA[2], *QB[2], *QC[2], *SQ = nullptr;
+    int *cset[2], *cSlow = nullptr;
     RoundsCfg cfg;
     bool ref = true, single_call = false;
     int cus = 256;
     long long round = 0;                                   // rounds run so far; set (round & 1) is consumed next
-    long long boundA = 0, boundB = 0, alive = 0, slow_pending = 0;     // host-side upper bounds of the queue sizes
+    long long boundA = 0, alive = 0, slow_pending = 0;     // host-side upper bounds: queue A of the current set, all fits in flight
     long long head = 0;                                    // ring allocator over the pool slots
     Batch b[FSQ_MAX_TICKETS];
     hipStream_t s = nullptr, s_finish = nullptr, hi = nullptr;
@@ -1410,7 +1523,7 @@ struct FsqFitQueue {
         ref = ((mode & 0xff) == FSQ_MODE_REF);
         cfg = read_cfg();
         unsigned char* ws = (unsigned char*)d_ws;
-        ctl = (int*)ws;     // per ping/pong set: {queue A, queue B, -, queue C}; [8] slow total, [9] slow queue, [16..] done
+        ctl = (int*)ws;     // two sets of queue counters (CNT_*), slow total, slow queue, done counters per ticket
         size_t o = 4096;
         c.cap = (long long)qcap;
         c.roi = (uint16_t*)(ws + o); o += al256(pool * 64);
@@ -1421,9 +1534,10 @@ struct FsqFitQueue {
         QA[1] = (double*)(ws + o); o += al256(qcap * A_LEN * 8);
         QB[0] = (double*)(ws + o); o += al256(qcap * B_LEN * 8);
         QB[1] = (double*)(ws + o); o += al256(qcap * B_LEN * 8);
-        QC = (double*)(ws + o); o += al256(qcap * C_LEN * 8);
+        QC[0] = (double*)(ws + o); o += al256(qcap * C_LEN * 8);
+        QC[1] = (double*)(ws + o); o += al256(qcap * C_LEN * 8);
         SQ = (double*)(ws + o); o += al256(qcap * A_LEN * 8);
-        cA[0] = ctl + 0; cA[1] = ctl + 4; cB[0] = ctl + 1; cB[1] = ctl + 5; cC[0] = ctl + 3; cC[1] = ctl + 7;
+        cset[0] = ctl; cset[1] = ctl + CNT_SET;
         cSlow = ctl + CTL_SLOW_CNT;
         c.slow_total = ctl + CTL_SLOW_TOTAL; c.done = ctl + CTL_DONE;
         c.tshift = single ? 31 : 32 - FSQ_TICKET_BITS;
@@ -1474,7 +1588,7 @@ struct FsqFitQueue {
         } else {
             const int cur = (int)(round & 1);
             FSQ_HIP_CHECK(hipMemsetAsync(c.done + t, 0, sizeof(int), s));
-            hipLaunchKernelGGL(kinit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c, B.a, QA[cur], cA[cur]);
+            hipLaunchKernelGGL(kinit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c, B.a, QA[cur], cset[cur] + CNT_A);
             B.state = T_FLIGHT;
             boundA += n; alive += n;
         }
@@ -1482,53 +1596,41 @@ struct FsqFitQueue {
         return FSQ_OK;
     }
 
-    // One round: Jacobian round over queue A of set cur (+ the slow queue), step round over queue B; results in set nxt.
+    // One round: Jacobian round over queue A of set cur (+ the slow queue), step round over queues B and C; results in set nxt.
     int one_round()
     {
         const int cur = (int)(round & 1), nxt = cur ^ 1;
-        // Grid sizing: one block per loop trip (16 fits in kA, 64 in kB), so blocks retire continuously.  The hardware
-        // dispatcher then balances the very uneven trip times, and small kernels of ANOTHER stream find free CU slots
-        // between them.  FSQ_TRIPS_PER_BLOCK=t gives every block t trips; t = 0 launches resident grids (8 waves per
-        // CU) that stride over the queue - measured 7% slower.
-        const long long full = (long long)cus * 8;
-        long long nB = boundA + boundB;
-        if (nB > alive) nB = alive;
-        const long long gA = (boundA + 15) / 16;    // kA: a block per trip
-        if (gA > 0)                                 // (kA also zeroes the counters of set nxt)
-            hipLaunchKernelGGL(kA_jacobian<true>, dim3((unsigned)gA), dim3(64), cfg.ka_lds_pad, s, c, QA[cur], cA[cur], QB[cur], cB[cur], SQ, cSlow, cA[nxt]);
+        // Grid sizing: one block per tile (16 or 8 fits in kA, 64 in kB), so blocks retire continuously.  The hardware
+        // dispatcher then balances the very uneven tile times, and small kernels of ANOTHER stream find free CU slots
+        // between them.
+        const int G = 64 / cfg.ka_lanes;
+        const long long gA = (boundA + G - 1) / G;
+        if (gA > 0 && cfg.ka_lanes == 8)            // (kA also zeroes the counters of set nxt)
+            hipLaunchKernelGGL((kA_jacobian<true, 8>), dim3((unsigned)gA), dim3(64), cfg.ka_lds_pad, s, c, QA[cur], cset[cur] + CNT_A, QB[cur], cset[cur], SQ, cSlow, cset[nxt]);
+        else if (gA > 0)
+            hipLaunchKernelGGL((kA_jacobian<true, 4>), dim3((unsigned)gA), dim3(64), cfg.ka_lds_pad, s, c, QA[cur], cset[cur] + CNT_A, QB[cur], cset[cur], SQ, cSlow, cset[nxt]);
         else
-            FSQ_HIP_CHECK(hipMemsetAsync(cA[nxt], 0, 4 * sizeof(int), s));
+            FSQ_HIP_CHECK(hipMemsetAsync(cset[nxt], 0, CNT_SET * sizeof(int), s));
         if (slow_pending > 0) {
             // fits that left the guarded operand ranges since the host last looked: the plain-division build takes them
-            // from the slow queue and appends their queue-B records to this round's
-            // (the slow queue may have grown since the host looked: size for all)
-            hipLaunchKernelGGL(kA_jacobian<false>, dim3((unsigned)std::min<long long>((alive + 15) / 16, (long long)cus * 8)), dim3(64), 0, s, c, SQ, cSlow, QB[cur], cB[cur], SQ, cSlow, cA[nxt]);
+            // from the slow queue and appends their queue-B records to this round's (the slow queue may have grown since the
+            // host looked: the kernel strides over whatever it finds)
+            hipLaunchKernelGGL((kA_jacobian<false, 4>), dim3((unsigned)std::min<long long>((alive + 15) / 16, (long long)cus * 8)), dim3(64), 0, s, c, SQ, cSlow, QB[cur], cset[cur], SQ, cSlow, cset[nxt]);
             FSQ_HIP_CHECK(hipMemsetAsync(cSlow, 0, sizeof(int), s));
-            nB += slow_pending;
-            if (alive < nB) alive = nB;
             slow_pending = 0;
         }
-        long long gB = (nB + 63) / 64;              // kB: a block per trip unless built with FSQ_KB_LOOP
-        if (KB_LOOP) {
-            if (cfg.trips > 0) gB = (gB + cfg.trips - 1) / cfg.trips;
-            else if (gB > full) gB = full;
+        // every fit in flight is in one of the four input lists of the step round by now (or terminated, or in the slow queue)
+        const long long gB = (alive + 63) / 64 + 4;
+        {
+            // With few fits left a round is pure launch + wave latency: lmpar then runs to the end wherever a fit is met
+            // (nothing is parked, no fit waits for the next round).
+            const bool staged = alive > cfg.two_pass_min && cfg.lm_first < 10;
+            KbLimits lims;
+            lims.lim[0] = staged ? std::min(cfg.lm_lo, cfg.lm_first) : 10; lims.lim[1] = staged ? cfg.lm_first : 10; lims.lim[2] = staged ? cfg.lm_first : 10; lims.lim[3] = 10;
+            if (ref) hipLaunchKernelGGL((kB_step<true>), dim3((unsigned)gB), dim3(64), cfg.kb_lds_pad, s, c, QB[cur], QC[cur], cset[cur], QA[nxt], QB[nxt], QC[nxt], cset[nxt], lims);
+            else hipLaunchKernelGGL((kB_step<false>), dim3((unsigned)gB), dim3(64), 0, s, c, QB[cur], QC[cur], cset[cur], QA[nxt], QB[nxt], QC[nxt], cset[nxt], lims);
         }
-        if (gB > 0) {
-            // first pass over queue B, then the fits it parked in queue C (blocks beyond the C count leave at once).
-            // With few fits left a round is pure launch + wave latency: lmpar then runs to the end in the first pass
-            // (nothing is parked) and the resume launch is skipped.
-            const bool two_pass = nB > cfg.two_pass_min && cfg.lm_first < 10;
-            const int lm_first = two_pass ? cfg.lm_first : 10;
-            if (ref) {
-                hipLaunchKernelGGL((kB_step<true, false>), dim3((unsigned)gB), dim3(64), cfg.kb_lds_pad, s, c, QB[cur], cB[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur], lm_first);
-                if (two_pass) hipLaunchKernelGGL((kB_step<true, true>), dim3((unsigned)gB), dim3(64), cfg.kb_lds_pad, s, c, QC, cC[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur], 10);
-            } else {
-                hipLaunchKernelGGL((kB_step<false, false>), dim3((unsigned)gB), dim3(64), 0, s, c, QB[cur], cB[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur], lm_first);
-                if (two_pass) hipLaunchKernelGGL((kB_step<false, true>), dim3((unsigned)gB), dim3(64), 0, s, c, QC, cC[cur], QA[nxt], cA[nxt], QB[nxt], cB[nxt], QC, cC[cur], 10);
-            }
-        }
-        boundB = nB;                                // every fit of this round ends in A[nxt], B[nxt] or is done
-        boundA = nB;
+        boundA = alive;                             // every fit of this round ends in a list of set nxt or is done
         round++;
         return FSQ_OK;
     }
@@ -1539,12 +1641,12 @@ struct FsqFitQueue {
         FSQ_HIP_CHECK(hipMemcpyAsync(h_ctl, ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, s));
         FSQ_HIP_CHECK(hipStreamSynchronize(s));
         const int cur = (int)(round & 1);
-        boundA = h_ctl[4 * cur];
-        boundB = h_ctl[4 * cur + 1];
+        const int* hc = h_ctl + CNT_SET * cur;
+        boundA = hc[CNT_A];
         slow_pending = h_ctl[CTL_SLOW_CNT];
-        alive = boundA + boundB + slow_pending;
+        alive = boundA + hc[CNT_BLO] + hc[CNT_BHI] + hc[CNT_C1] + hc[CNT_C3] + slow_pending;
         g_last_slow.store(h_ctl[CTL_SLOW_TOTAL]);
-        if (cfg.trace) fprintf(stderr, "round %lld: A=%lld B=%lld slow=%lld total_slow=%d\n", round - 1, boundA, boundB, slow_pending, h_ctl[CTL_SLOW_TOTAL]);
+        if (cfg.trace) fprintf(stderr, "round %lld: A=%lld B=%d+%d C=%d+%d slow=%lld total_slow=%d\n", round - 1, boundA, hc[CNT_BLO], hc[CNT_BHI], hc[CNT_C1], hc[CNT_C3], slow_pending, h_ctl[CTL_SLOW_TOTAL]);
         int fin = 0;
         for (auto& t : b) {
             if (t.state != T_FLIGHT || h_ctl[CTL_DONE + t.a.ticket] < t.a.n) continue;

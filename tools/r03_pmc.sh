@@ -21,7 +21,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in glob.glob(O + "/pmc_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        k = "kA" if "kA_jacobian<true>" in n else "kAslow" if "kA_jacobian<false>" in n else "kB" if "kB_step<true, false>" in n else "kBres" if "kB_step<true, true>" in n else None
+        k = "kA" if "kA_jacobian<true" in n else "kAslow" if "kA_jacobian<false" in n else "kB" if "kB_step<true" in n else "kBres" if "kB_step<false" in n else None
         if k: acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
 with open(O + "/pmc_summary.txt", "w") as out:
     names = sorted({c for k in acc for c in acc[k]})
