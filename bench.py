@@ -44,6 +44,15 @@ def make_fields(seeds, shape, n_spots):
     return out
 
 
+def library_sha16(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(imgs, cand, counts, offsets, n_threads):
     """The oracle (C restatement of the reference) on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -131,10 +140,20 @@ def main():
         # stream (stream pipeline: the fit queue's own stream, busy from the first to the last round of the timed
         # region; lanes: the time at least one lane's fit launch was running)
         achieved = total * a.steps * FLOP_PER_FIT / (busy_ms * 1e-3) / 1e12
-        prof = {}
+        # PMC-derived figures (HBM bytes, issue fractions) cannot be collected inside this run (rocprofv3 --pmc serialises the
+        # kernels): they come from profiles/fit_counters_latest.json, which records the library build it was taken on, and are
+        # only reported when that is the library loaded now - otherwise null with stale = true.
+        prof, from_profile = {}, {"stale": True}
         ppath = os.path.join(ROOT, "profiles", "fit_counters_latest.json")
+        lib_sha = library_sha16(N.LIB_PATH)
         if os.path.exists(ppath):
             prof = json.load(open(ppath))
+            if prof.get("library_sha16") == lib_sha:
+                from_profile = dict(prof, stale=False, note="not measured in this run: separate rocprofv3 --pmc passes of the same library "
+                                                            "on %s fields per step (tools/collect_profiles_r03.sh)" % prof.get("fields_per_step"))
+            else:
+                from_profile = {"stale": True, "library_sha16_of_profile": prof.get("library_sha16"), "library_sha16_loaded": lib_sha}
+                prof = {}
         traffic = prof.get("fit_kernel_hbm_bytes_per_1024_field_step")
         if traffic is not None:
             traffic = traffic * (a.fields / 1024.0)
@@ -158,8 +177,7 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
                          "fits_per_step": int(total), "busy_ms": busy_ms, "busy_ms_per_step": busy_ms / a.steps,
                          "launches": fit_launches, "flop_per_fit": FLOP_PER_FIT,
-                         "valu_issue_frac": prof.get("valu_issue_frac"), "executed_valu_per_fit": prof.get("executed_valu_per_fit"),
-                         "counters_source": prof.get("source"),
+                         "from_profile": from_profile,
                          "hbm": {"algorithmic_bytes_per_fit": 98,
                                  "algorithmic_GBps": 98.0 * total * a.steps / (busy_ms * 1e-3) / 1e9,
                                  "traffic_GBps": (traffic * a.steps / (busy_ms * 1e-3) / 1e9) if traffic else None,
@@ -184,41 +202,53 @@ REG_BYTES_PER_PX = 2 * (2 + 8) + 2 * 4 * 8 + (16 + 16 + 8) + 4 * 8 + 8 + 2 * 8  
 # read of both half spectra.  = 180 B per pixel = 45 MiB per 512x512 pair ("halve with R2C").
 
 
-def bench_registration(a, torch, dist, D, E, N):
+def measure_registration(torch, E, N, size, spots, steps, warmup, rank=0, barrier=None):
     """configs[2]'s registration step: consecutive cycle frames of channel 0 registered at upsample_factor 20
-    (SequenceExperiment.offsets_from_frames, flexlibrary.py:1717-1741): 32 fields x 7 pairs of 512x512 uint16 frames per
-    step, resident in HBM.  value = pairs per second."""
+    (SequenceExperiment.offsets_from_frames, flexlibrary.py:1717-1741): 32 fields x 7 pairs of uint16 frames per step, resident
+    in HBM.  -> dict(pairs, wall seconds for `steps` calls, kernel ms per call, algorithmic bytes per call)."""
     from fluorosequencingimageanalysis_amd import phase_correlate as PC
     from fluorosequencingimageanalysis_amd import synth
-    rank, world, local = D.init_from_env()
-    local = local % torch.cuda.device_count()
-    torch.cuda.set_device(local)
-    H = W = a.size
-    stacks = [synth.make_cycle_stack(100 + 7 * rank + f, n_cycles=8, shape=(H, W), n_spots=a.spots)[0] for f in range(4)]
+    H = W = size
+    stacks = [synth.make_cycle_stack(100 + 7 * rank + f, n_cycles=8, shape=(H, W), n_spots=spots)[0] for f in range(4)]
     ref = np.tile(np.concatenate([s_[:-1] for s_ in stacks]), (8, 1, 1))
     reg = np.tile(np.concatenate([s_[1:] for s_ in stacks]), (8, 1, 1))
     n = len(ref)
     d_ref, d_reg = E.to_device_u16(ref), E.to_device_u16(reg)
     R = PC.Registrar(n, H, W, 20, N.DTYPE_U16)
     out = R.register(d_ref, d_reg)
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         R.register(d_ref, d_reg, out)
-    _barrier(torch, dist, world)
+    if barrier is not None:
+        barrier()
+    torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(a.steps):
+    for _ in range(steps):
         R.register(d_ref, d_reg, out)
     ev1.record()
-    _barrier(torch, dist, world)
+    if barrier is not None:
+        barrier()
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    return {"pairs": n, "seconds": dt, "launch_ms": ev0.elapsed_time(ev1) / steps, "bytes_per_call": REG_BYTES_PER_PX * H * W * n}
+
+
+def bench_registration(a, torch, dist, D, E, N):
+    """python bench.py --config 3: the registration step alone.  value = pairs per second."""
+    rank, world, local = D.init_from_env()
+    local = local % torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    H = W = a.size
+    m = measure_registration(torch, E, N, a.size, a.spots, a.steps, a.warmup, rank, lambda: _barrier(torch, dist, world))
+    n, dt = m["pairs"], m["seconds"]
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0])
     if rank == 0:
-        ms = ev0.elapsed_time(ev1) / a.steps
-        by = REG_BYTES_PER_PX * H * W * n
+        ms = m["launch_ms"]
+        by = m["bytes_per_call"]
         print(json.dumps({
             "metric": "registration_pairs_per_sec", "value": n * world * a.steps / dt, "unit": "pairs/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
@@ -373,8 +403,12 @@ def run_lanes(a, torch, dist, D, E, N, d_img, prm, dev, rank, world):
 
 
 def extras(a, torch, E, N, pflib, imgs, d_img, prm, dev):
-    """Side measurements SURVEY 8d lists next to the headline: the same stream pipeline with every step's images
-    uploaded from pinned host memory inside the timed region, and the rate of the dict-materialising pflib surface."""
+    """Side measurements SURVEY 8d lists next to the headline, taken in the same run: the stream pipeline with every step's
+    images uploaded inside the timed region; the dict-materialising pflib surface; the command line end to end (TIFF -> pickle +
+    CSV); the registration step of configs[2]; the tracking and photometry kernels."""
+    import shutil
+    import subprocess
+    import tempfile
     out = {}
     n = min(a.steps, 6)
     pinned = torch.from_numpy(imgs.view(np.int16)).pin_memory()
@@ -395,17 +429,69 @@ def extras(a, torch, E, N, pflib, imgs, d_img, prm, dev):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     pipe.close()
+    del pipe, bufs, pinned
     out["h2d_inclusive_fields_per_sec"] = a.fields * n / dt
     out["h2d_inclusive_note"] = "%d steps, each step's %d fields copied from pinned host memory (%.0f MiB) on the side stream" % (
         n, a.fields, imgs.nbytes / 2**20)
-    m = min(64, a.fields)
-    pflib.find_peptides_batch(imgs[:2])
+    # the drop-in surface: host stack in, list of dicts of 12-tuples out (H2D, streamed chunks, D2H, Python objects)
+    pflib.find_peptides_batch(imgs[:256])
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        d = pflib.find_peptides_batch(imgs)
+        dt = time.perf_counter() - t0
+        npk = sum(len(x) for x in d)
+        del d
+        best = dt if best is None else min(best, dt)
+    out["find_peptides_batch_fields_per_sec"] = len(imgs) / best
+    out["find_peptides_batch_note"] = ("pflib.find_peptides_batch on %d host fields -> list of dicts of 12-tuples (pinned H2D, chunks "
+                                       "of %d fields streamed through a cached pipeline, D2H, dicts built by a worker thread; "
+                                       "%d peaks)" % (len(imgs), pflib.CHUNK_PIXELS // (a.size * a.size), npk))
     t0 = time.perf_counter()
-    d = pflib.find_peptides_batch(imgs[:m])
+    rec, counts, _fmt = pflib.find_peptides_records(imgs)
     dt = time.perf_counter() - t0
-    out["find_peptides_batch_fields_per_sec"] = m / dt
-    out["find_peptides_batch_note"] = ("pflib.find_peptides_batch on %d host fields -> list of dicts of 12-tuples "
-                                       "(H2D + one stand-alone GPU pass + D2H + Python tuples; %d peaks)" % (m, sum(len(x) for x in d)))
+    out["find_peptides_records_fields_per_sec"] = len(imgs) / dt
+    out["find_peptides_records_note"] = "the same call returning the peak records as byte tables (no Python objects per peak)"
+    # the command line end to end: a directory of 16-bit TIFFs -> pickle + CSV per image
+    m = min(256, len(imgs))
+    tmp = tempfile.mkdtemp(prefix="fsq_bench_cli_")
+    try:
+        from PIL import Image
+        from fluorosequencingimageanalysis_amd import basic_image_script as cli
+        for i in range(m):
+            Image.fromarray(imgs[i]).save(os.path.join(tmp, "field%04d.tif" % i), format="TIFF")
+        t0 = time.perf_counter()
+        res = cli.main(["-L", os.path.join(tmp, "log.txt"), tmp])
+        dt = time.perf_counter() - t0
+        out["cli_images_per_sec"] = len(res) / dt
+        out["cli_note"] = ("basic_image_script over %d synthetic 16-bit TIFFs of %dx%d in one process: TIFF -> PNG conversion, read, "
+                           "fit, protocol-0 pickle (%.1f MB per image) + CSV per image; %d images processed"
+                           % (m, a.size, a.size, os.path.getsize(next(iter(res.values()))[1]) / 1e6 if res else 0.0, len(res)))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    pflib.release_gpu_resources()
+    # registration (configs[2]'s step), 10 calls
+    r = measure_registration(torch, E, N, a.size, a.spots, 10, 2)
+    out["registration_pairs_per_sec"] = r["pairs"] * 10 / r["seconds"]
+    out["registration_hbm_frac"] = r["bytes_per_call"] / (r["launch_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS
+    out["registration_note"] = "%d pairs of %dx%d uint16 frames per call, upsample_factor 20, %.2f ms of kernel time per call" % (
+        r["pairs"], a.size, a.size, r["launch_ms"])
+    # tracking and photometry kernels (their own processes: tools/bench_tracking.py, tools/bench_photometry.py)
+    torch.cuda.empty_cache()
+    for script in ("bench_tracking.py", "bench_photometry.py"):
+        try:
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script)], capture_output=True, text=True, timeout=300)
+            for line in p.stdout.splitlines():
+                if line.startswith("{"):
+                    j = json.loads(line)
+                    key = {"greedy_tracking_fields_per_sec": "tracking_fields_per_sec",
+                           "centroid_tracking_spot_frames_per_sec": "centroid_tracking_spot_frames_per_sec",
+                           "mexican_hat_spots_per_sec": "photometry_spots_per_sec"}.get(j["metric"], j["metric"])
+                    out[key] = j["value"]
+            if p.returncode != 0:
+                out[script + "_error"] = p.stderr[-300:]
+        except Exception as e:      # noqa: BLE001 - a side measurement must not take the headline down
+            out[script + "_error"] = repr(e)
     return out
 
 

@@ -94,5 +94,17 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as e:      # noqa: BLE001
+        if isinstance(e, SystemExit):
+            raise
+        # under torchrun a failed rank must not leave its peers waiting in a collective: report and leave without the
+        # interpreter's orderly shutdown (which would block in the process group's destructor); torchrun then ends the job
+        import traceback
+        traceback.print_exc()
+        logging.getLogger().exception(e)
+        logging.shutdown()
+        sys.stderr.flush()
+        os._exit(1) if distributed.world_size() > 1 else sys.exit(1)
     sys.exit(0)

@@ -96,80 +96,105 @@ def _partition(weights_or_n, world, partition):
     raise ValueError("partition must be 'lpt' or 'round_robin'")
 
 
-def find_peptides_sharded(images, partition="lpt", dst=0, **find_peptides_parameters):
-    """pflib.find_peptides over a stack uint16[n, H, W] with the fields sharded over the ranks of the process group
-    (one process per GPU).  Every rank calls it with the same stack and parameters.
+def _all_ranks_ok(local_error):
+    """Collective error check: every rank reports whether its part of the work raised; if any did, EVERY rank raises (the
+    failing one its own exception, the others a RuntimeError naming it) instead of leaving its peers waiting in the next
+    collective until the backend times out."""
+    import torch.distributed as dist
+    reports = [None] * dist.get_world_size()
+    dist.all_gather_object(reports, None if local_error is None else "%s: %s" % (type(local_error).__name__, local_error))
+    if local_error is not None:
+        raise local_error
+    bad = [(r, m) for r, m in enumerate(reports) if m is not None]
+    if bad:
+        raise RuntimeError("rank %d failed: %s" % bad[0])
 
+
+def find_peptides_sharded(images, partition="lpt", dst=0, n_fields=None, **find_peptides_parameters):
+    """pflib.find_peptides over n same-shaped fields sharded over the ranks of the process group (one process per GPU).
+    Every rank calls it with the same arguments.
+
+    images: a stack uint16[n, H, W] every rank holds, or a LOADER - a callable taking a list of field indices and returning
+    their stack - together with n_fields, so that a rank only ever holds the fields it works on.
     partition='lpt' balances the fields by candidate count with the reference's longest-processing-time rule
-    (pflib.parallel_image_batch, pflib.py:1043-1069: candidates are counted first, then the fields are dealt out);
-    'round_robin' gives field i to rank i mod world.  Each rank runs detect -> fit -> consolidate on its share; the
-    only exchange is the gather of the peak records to `dst` (RCCL p2p, gather_tables).  Returns the list of n dicts
-    (identical to pflib.find_peptides_batch on one GPU) on `dst` and None on the other ranks."""
+    (pflib.parallel_image_batch, pflib.py:1043-1069: candidates are counted first - every rank counts a round-robin share in
+    one detection pass, 2 % of the work of a fit pass - then the fields are dealt out); 'round_robin' gives field i to rank
+    i mod world.  Each rank streams its share through the same pipeline as pflib.find_peptides_batch; the only exchange is
+    the gather of the peak records to `dst` (RCCL p2p, gather_tables).  Returns the list of n dicts (identical to
+    pflib.find_peptides_batch on one GPU) on `dst` and None on the other ranks.  A rank that fails makes every rank raise."""
     import torch
     import torch.distributed as dist
-    from . import _native as N
     from . import engine as E
     from . import pflib
     world, rank = world_size(), get_rank()
+    if callable(images):
+        if n_fields is None:
+            raise ValueError("a loader needs n_fields")
+        loader, n = images, int(n_fields)
+    else:
+        stack = np.asarray(images)
+        if stack.ndim != 3:
+            raise ValueError("images must have shape (n, H, W)")
+        loader, n = (lambda idx: stack[idx]), len(stack)
     if world == 1:
-        return pflib.find_peptides_batch(images, **find_peptides_parameters)
-    imgs, fmt = E.as_pixel_fields(images)
-    if imgs.ndim != 3:
-        raise ValueError("images must have shape (n, H, W)")
-    n, H, W = imgs.shape
+        return pflib.find_peptides_batch(loader(list(range(n))), **find_peptides_parameters)
     fp = dict(find_peptides_parameters)
-    radius = fp.get("consolidation_radius", 4)
-    if radius < 2:
+    if fp.get("consolidation_radius", 4) < 2:
         raise ValueError("consolidation_radius must be at least 2")
     if fp.get("fit_type", "gauss") != "gauss":
         raise NotImplementedError("fit_type='monte_carlo' is not reproduced (pflib.py:117-177)")
-    prm = E.detect_params(fp.get("median_filter_size", 5), fp.get("correlation_matrix", pflib.default_correlation_matrix),
-                          fp.get("c_std", 2), fmt)
     dev = torch.device("cuda", torch.cuda.current_device())
+    gloo = dist.get_backend() == "gloo"
+    held = {}                                   # fields this rank has loaded: index -> array
 
-    def run_share(idx, fit):
-        if not idx:
-            return None, None
-        eng = E.Engine(len(idx), H, W, device=dev)
-        d_img = E.to_device_u16(imgs[idx], dev)
-        if fit:
-            eng.run(d_img, prm, fp.get("r_2_threshold", 0.7), radius, N.MODE_REF, pflib.PY2_ROUND)
-        else:
-            eng.detect(d_img, prm)
-        return eng, d_img
+    def load(idx):
+        need = [i for i in idx if i not in held]
+        if need:
+            for i, a in zip(need, loader(need)):
+                held[i] = a
+        return np.stack([held[i] for i in idx]) if idx else None
 
+    err, parts, rec, counts, fmt = None, None, None, None, 0
+    try:
+        if partition == "lpt":
+            mine = shard_fields(n, rank, world)
+            w = torch.zeros(n, dtype=torch.int64)
+            if mine:
+                w[mine] = torch.from_numpy(pflib.count_candidates(load(mine), **fp))
+    except Exception as e:      # noqa: BLE001 - reported to every rank below
+        err = e
+    _all_ranks_ok(err)
     if partition == "lpt":
-        # count candidates on a round-robin share, exchange the counts, deal the fields out
-        mine = shard_fields(n, rank, world)
-        eng, _ = run_share(mine, fit=False)
-        w = torch.zeros(n, dtype=torch.int64)
-        if eng is not None:
-            w[mine] = eng.counts[:len(mine)].cpu().long()
-        w = w.to(dev) if dist.get_backend() != "gloo" else w
+        w = w if gloo else w.to(dev)
         dist.all_reduce(w)
         parts = _partition([int(x) for x in w.cpu()], world, "lpt")
-        del eng
     else:
         parts = _partition(n, world, partition)
     mine = parts[rank]
-    eng, d_img = run_share(mine, fit=True)
-    if eng is not None:
-        rec, offs = eng.peak_records(d_img)
-        per_field = (offs[1:] - offs[:-1]).to(torch.int32)
-        per_field = torch.where(eng.nkeep[:len(mine)] < 0, eng.nkeep[:len(mine)], per_field).reshape(-1, 1)
-    else:
-        rec = torch.empty((0, E.PEAK_RECORD_BYTES), dtype=torch.uint8, device=dev)
-        per_field = torch.empty((0, 1), dtype=torch.int32, device=dev)
-    table, _ = gather_tables(rec, dst)
-    fields, _ = gather_tables(per_field.contiguous(), dst)
+    try:
+        for i in [i for i in held if i not in mine]:
+            del held[i]
+        if mine:
+            rec, counts, fmt = pflib.find_peptides_records(load(mine), **fp)
+        else:
+            rec, counts = np.zeros((0, E.PEAK_RECORD_BYTES), np.uint8), np.zeros(0, np.int32)
+        held.clear()
+    except Exception as e:      # noqa: BLE001
+        err = e
+    _all_ranks_ok(err)
+    t_rec = torch.from_numpy(np.ascontiguousarray(rec))
+    t_cnt = torch.from_numpy(np.ascontiguousarray(counts, dtype=np.int32).reshape(-1, 1))
+    if not gloo:
+        t_rec, t_cnt = t_rec.to(dev), t_cnt.to(dev)
+    table, _ = gather_tables(t_rec, dst)
+    fields, _ = gather_tables(t_cnt, dst)
+    fmts = [None] * world
+    dist.all_gather_object(fmts, int(fmt) if mine else None)
     if rank != dst:
         return None
-    rows, fit, sub = E.split_peak_records(table.cpu().numpy(), fmt)
-    nk = fields.cpu().numpy().reshape(-1)
+    fmt = next((f for f in fmts if f is not None), 0)
+    dicts = pflib.records_to_dicts(table.cpu().numpy(), fields.cpu().numpy().reshape(-1), fmt)
     order = [i for p in parts for i in p]                  # global field index of every gathered per-field entry
-    failed = set(int(k) for k in np.nonzero(nk < 0)[0])
-    offs = np.concatenate([[0], np.cumsum(np.maximum(nk, 0))])
-    dicts = pflib._records_to_dicts(rows, fit, sub, offs, failed)
     out = [None] * n
     for k, i in enumerate(order):
         out[i] = dicts[k]
@@ -183,7 +208,11 @@ def image_batch_sharded(image_paths, find_peptides_parameters=None, timestamp_ep
     """pflib.parallel_image_batch with the ranks of the process group as its workers (pflib.py:1000-1111): the images
     are read and their candidates counted (each rank takes a round-robin share of that), dealt out by the reference's
     longest-processing-time rule, every rank runs pflib.image_batch on its share (writing its own pickle / CSV files:
-    the file system is the reference's gather too) and the per-rank result dicts are merged on all ranks."""
+    the file system is the reference's gather too) and the per-rank result dicts are merged on all ranks.
+    Keys of the result are the ORIGINAL image paths, as the reference's docstring and its single-process branch have them
+    (pflib.py:1013-1016, 949-996); its multi-process branch keys by the converted .png paths instead (pflib.py:1046-1054
+    hands image_batch the converted paths), an inconsistency of the reference that is not reproduced.
+    A rank that fails (as opposed to an image that fails, which is logged and skipped) makes every rank raise."""
     import torch.distributed as dist
     from . import pflib
     world, rank = world_size(), get_rank()
@@ -198,18 +227,36 @@ def image_batch_sharded(image_paths, find_peptides_parameters=None, timestamp_ep
     fp = dict(find_peptides_parameters or {})
     det = {k: fp[k] for k in ("median_filter_size", "correlation_matrix", "c_std") if k in fp}
     mine = shard_fields(len(paths), rank, world)
-    local = pflib._candidate_counts([paths[i] for i in mine], det)          # unreadable images count as None
+    err, local = None, []
+    try:
+        local = pflib._candidate_counts([paths[i] for i in mine], det)      # unreadable images count as None
+    except Exception as e:      # noqa: BLE001 - reported to every rank below
+        err = e
+    _all_ranks_ok(err)
     gathered = [None] * world
     dist.all_gather_object(gathered, list(zip(mine, local)))
     counts = dict(kv for part in gathered for kv in part)
     usable = [i for i in range(len(paths)) if counts.get(i) is not None]
     parts = lpt_partition([counts[i] for i in usable], world)
     my_paths = [paths[usable[k]] for k in sorted(parts[rank])]
-    res = pflib.image_batch(my_paths, find_peptides_parameters, timestamp_epoch)
+    res = {}
+    try:
+        res = pflib.image_batch(my_paths, find_peptides_parameters, timestamp_epoch)
+    except Exception as e:      # noqa: BLE001
+        err = e
+    _all_ranks_ok(err)
     merged = [None] * world
     dist.all_gather_object(merged, res)
     out = {}
     for part in merged:
         for k, v in part.items():
             out.setdefault(k, v)
-    return out
+    return {p: out[p] for p in paths if p in out}
+
+
+def lpt_assignment(image_paths, counts, world):
+    """Which rank image_batch_sharded gives every usable image of a list to (for tests / logs): {path: rank}."""
+    paths = list(dict.fromkeys(os.path.abspath(p) for p in image_paths))
+    usable = [i for i in range(len(paths)) if counts[i] is not None]
+    parts = lpt_partition([counts[i] for i in usable], world)
+    return {paths[usable[k]]: r for r in range(world) for k in parts[r]}

@@ -31,12 +31,18 @@ def to_device_u16(images, device=None):
 
 
 def as_u16_fields(image):
-    """Validate one image / a stack like the reference's `image.astype(np.int64)` input, as uint16."""
+    """One image / a stack as uint16, the way the reference's `image.astype(np.int64)` (pflib.py:241, 443) reads its input:
+    integer pixels as they are, floating-point pixels truncated toward zero.  The GPU path works on 16-bit pixels: values
+    outside [0, 65535] (or not finite) raise NotImplementedError."""
     a = np.asarray(image)
     if a.dtype == np.uint16:
         return np.ascontiguousarray(a)
-    if a.dtype.kind not in "iub":
-        raise NotImplementedError("only integer pixel data is supported (got %s)" % a.dtype)
+    if a.dtype.kind == "f":
+        if a.size and not np.isfinite(a).all():
+            raise NotImplementedError("non-finite pixel values are not supported by the GPU path")
+        a = a.astype(np.int64)                      # truncation toward zero, as the reference
+    elif a.dtype.kind not in "iub":
+        raise NotImplementedError("only real-valued pixel data is supported (got %s)" % a.dtype)
     if a.size and (a.min() < 0 or a.max() > 65535):
         raise NotImplementedError("pixel values outside [0, 65535] are not supported by the GPU path")
     return np.ascontiguousarray(a.astype(np.uint16))
@@ -390,11 +396,20 @@ class StreamPipeline:
         self.engines = [Engine(self.n_fields, self.H, self.W, device=self.dev, cand_per_field=cand_per_field,
                                fit_workspace=False, shared_ws=self.shared_ws) for _ in range(self.depth)]
         per = int(cand_per_batch or self.engines[0].cap)
-        self.cand_per_batch = per
-        # a batch's slots are held until its last fit is done; the queue only ever holds the fits still alive
+        self.mode = mode
+        self._inject_below_arg = inject_below
+        self.queue = None
+        self._make_queue(per)
+
+    def _make_queue(self, per):
+        """(Re)build the fit queue for batches of up to `per` candidates.  A batch's pool slots are held until its last fit is
+        done; the queue itself only ever holds the fits still alive."""
+        if self.queue is not None:
+            self.queue.close()
+        self.cand_per_batch = per = int(per)
         self.queue = FitQueue(pool_slots=min((self.depth + 2) * per, (1 << 27) - 1), queue_cap=2 * per + per // 2,
-                              mode=mode, device=self.dev)
-        self.inject_below = int(inject_below if inject_below is not None else per // 4)
+                              mode=self.mode, device=self.dev)
+        self.inject_below = int(self._inject_below_arg if self._inject_below_arg is not None else per // 4)
 
     def run(self, jobs, on_done=None, r2_threshold=0.7, radius=4, py2_round=True):
         """jobs: iterable of (d_img, detect_params).  on_done(job_index, engine, total) is called, in order of
@@ -427,8 +442,12 @@ class StreamPipeline:
                         inflight[t] = pending
                         pending = None
                         continue                                 # detect the job after this one before advancing
-                    if not inflight:
-                        raise MemoryError("a batch of %d candidates does not fit the fit queue" % total)
+                    if not inflight:        # the queue is empty and still too small for this batch: size it for the batch
+                        if total <= self.cand_per_batch:
+                            raise MemoryError("a batch of %d candidates does not fit the fit queue" % total)
+                        self._make_queue(total + total // 4 + 1024)
+                        q = self.queue
+                        continue
                 if not inflight:
                     if pending is None and exhausted:
                         break

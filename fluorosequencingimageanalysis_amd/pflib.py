@@ -8,11 +8,16 @@ DESIGN.md).  There is no CPU fallback: without libfsq_hip.so / a GPU every compu
 Batch extension (not in the reference): `find_peptides_batch(images, ...)` runs many same-sized
 fields in one pass and is what bench.py and the multi-GPU driver use.
 """
+import atexit
+import collections
+import concurrent.futures
 import csv
+import gc
 import logging
 import math
 import os
 import pickle
+import threading
 import time
 
 import numpy as np
@@ -29,6 +34,43 @@ default_correlation_matrix = _engine.DEFAULT_CORRELATION_MATRIX.copy()      # pf
 PY2_ROUND = True
 
 
+# ---- GPU resources kept between calls ---------------------------------------------------------------------------------
+# Building an Engine / StreamPipeline means allocating its workspaces (GBs for a pipeline); the drop-in functions are called
+# image after image, batch after batch, so the objects are kept in a small process-wide LRU cache keyed by the batch shape.
+_CACHE = collections.OrderedDict()
+_CACHE_LOCK = threading.RLock()
+MAX_CACHED_RESOURCES = 4
+
+
+def _cached(key, factory):
+    with _CACHE_LOCK:
+        if key in _CACHE:
+            _CACHE.move_to_end(key)
+            return _CACHE[key]
+        while len(_CACHE) >= MAX_CACHED_RESOURCES:
+            _, old = _CACHE.popitem(last=False)
+            close = getattr(old, "close", None)
+            if close is not None:
+                close()
+        obj = _CACHE[key] = factory()
+        return obj
+
+
+def release_gpu_resources():
+    """Free the cached engines / pipelines (they are re-created on demand)."""
+    with _CACHE_LOCK:
+        while _CACHE:
+            _, old = _CACHE.popitem()
+            close = getattr(old, "close", None)
+            if close is not None:
+                close()
+
+
+def _device_key():
+    torch = _engine._torch()
+    return torch.cuda.current_device()
+
+
 def _psf_candidates(image, median_filter_size=5, correlation_matrix=default_correlation_matrix, c_std=2, **kwargs):
     """Candidate pixels for PSF fitting, as a list [(h, w), ...] in raster order.  Reference pflib.py:217-258."""
     img, fmt = _engine.as_pixel_fields(image)
@@ -36,9 +78,10 @@ def _psf_candidates(image, median_filter_size=5, correlation_matrix=default_corr
     if img.ndim != 2:
         raise ValueError("image must be two-dimensional")
     H, W = img.shape
-    eng = _engine.Engine(1, H, W)
-    total = eng.detect(_engine.to_device_u16(img), prm)
-    cand, _, _ = eng.candidates(total)
+    eng = _cached(("detect", _device_key(), H, W), lambda: _engine.Engine(1, H, W, fit_workspace=False))
+    with _CACHE_LOCK:
+        total = eng.detect(_engine.to_device_u16(img), prm)
+        cand, _, _ = eng.candidates(total)
     return [(int(h), int(w)) for _, h, w in cand]
 
 
@@ -49,14 +92,32 @@ def _fit_2d_gaussian(subimage, implementation='agpy'):
     assert subimage.shape[0] == 5 and subimage.shape[1] == 5
     if implementation != 'agpy':
         raise NotImplementedError("Currently, only agpy is supported.")
-    rows, d_rows = _engine.fit_rois(subimage.reshape(1, 5, 5))
     torch = _engine._torch()
-    fit = torch.empty((1, 25), dtype=torch.float64, device=d_rows.device)
-    N.check(N.lib().fsq_fit_images(d_rows.data_ptr(), None, 1, fit.data_ptr(), torch.cuda.current_stream().cuda_stream),
-            "fsq_fit_images")
-    r = rows[0]
+    ws = _cached(("roi1", _device_key()), lambda: _Roi1Workspace())
+    with _CACHE_LOCK:
+        r, fit = ws.fit(subimage)
     return (float(r["p2"]), float(r["p3"]), float(r["H"]), float(r["A"]), float(r["sigma_h"]), float(r["sigma_w"]),
-            float(r["theta"]), fit.cpu().numpy().reshape(5, 5))
+            float(r["theta"]), fit)
+
+
+class _Roi1Workspace:
+    """Device buffers of _fit_2d_gaussian (one 5x5 ROI per call)."""
+
+    def __init__(self):
+        torch = _engine._torch()
+        self.torch = torch
+        self.rows = torch.empty((1, 128), dtype=torch.uint8, device="cuda")
+        self.ws = torch.empty(N.lib().fsq_fit_workspace_bytes(1), dtype=torch.uint8, device="cuda")
+        self.fit_img = torch.empty((1, 25), dtype=torch.float64, device="cuda")
+
+    def fit(self, subimage):
+        torch = self.torch
+        d = _engine.to_device_u16(_engine.as_u16_fields(subimage).reshape(1, 25))
+        s = torch.cuda.current_stream().cuda_stream
+        N.check(N.lib().fsq_fit_rois(d.data_ptr(), 1, N.MODE_REF, self.rows.data_ptr(), self.ws.data_ptr(), self.ws.numel(), s),
+                "fsq_fit_rois")
+        N.check(N.lib().fsq_fit_images(self.rows.data_ptr(), None, 1, self.fit_img.data_ptr(), s), "fsq_fit_images")
+        return self.rows.cpu().numpy().view(N.ROW_DTYPE).reshape(-1)[0], self.fit_img.cpu().numpy().reshape(5, 5)
 
 
 def illumina_s_n(sub_img):
@@ -72,23 +133,30 @@ def illumina_s_n(sub_img):
 
 def _records_to_dicts(rows, fit, sub, offs, failed=()):
     """Peak records of a batch (engine.split_peak_records) -> one {(h, w): 12-tuple} per field, in the reference's
-    dict order (pflib.py:396-407, 475, 514-519); fields listed in `failed` give an AssertionError instance instead."""
-    cols = [rows[k].tolist() for k in ("key_h", "key_w")]
-    f64 = [[np.float64(x) for x in rows[k]] for k in ("h0", "w0", "H", "A", "sigma_h", "sigma_w", "theta")]
-    rmse = rows["rmse"].tolist()
-    r2 = [np.float64(x) for x in rows["r2"]]
-    s_n = [np.float64(x) for x in rows["s_n"]]
-    out = []
-    for f in range(len(offs) - 1):
-        if f in failed:
-            out.append(AssertionError("field %d: re-keyed peak collides with an existing key (pflib.py:518)" % f))
-            continue
-        d = {}
-        for i in range(int(offs[f]), int(offs[f + 1])):
-            d[(cols[0][i], cols[1][i])] = (f64[0][i], f64[1][i], f64[2][i], f64[3][i], f64[4][i], f64[5][i], f64[6][i],
-                                           sub[i], fit[i], rmse[i], r2[i], s_n[i])
-        out.append(d)
-    return out
+    dict order (pflib.py:396-407, 475, 514-519); fields listed in `failed` give an AssertionError instance instead.
+    Built column-wise: the value types are the reference's (numpy.float64 scalars, a Python float for rmse, 5x5 arrays -
+    views of the batch's sub_img / fit_img blocks), the tuples are zipped together and the dicts filled by the interpreter's
+    C loops; the cyclic garbage collector is held off meanwhile (millions of fresh containers, none of them cyclic)."""
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        cols = [list(np.ascontiguousarray(rows[k])) for k in ("h0", "w0", "H", "A", "sigma_h", "sigma_w", "theta")]
+        rmse = rows["rmse"].tolist()
+        r2 = list(np.ascontiguousarray(rows["r2"]))
+        s_n = list(np.ascontiguousarray(rows["s_n"]))
+        tuples = list(zip(*cols, list(sub), list(fit), rmse, r2, s_n))
+        keys = list(zip(rows["key_h"].tolist(), rows["key_w"].tolist()))
+        offs = [int(x) for x in offs]
+        out = []
+        for f in range(len(offs) - 1):
+            if f in failed:
+                out.append(AssertionError("field %d: re-keyed peak collides with an existing key (pflib.py:518)" % f))
+            else:
+                out.append(dict(zip(keys[offs[f]:offs[f + 1]], tuples[offs[f]:offs[f + 1]])))
+        return out
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 def _engine_dicts(eng, d_img, pixel_format=N.PIXELS_U16):
@@ -100,66 +168,210 @@ def _engine_dicts(eng, d_img, pixel_format=N.PIXELS_U16):
     return _records_to_dicts(rows, fit, sub, offs.cpu().numpy(), failed)
 
 
-#: find_peptides_batch works stacks larger than this many pixels as a stream of chunks (engine.StreamPipeline)
+#: find_peptides_batch streams a stack through the GPU in chunks of about this many pixels (engine.StreamPipeline)
+CHUNK_PIXELS = 128 * 512 * 512
+#: (kept for callers that tuned it: the largest stack that used to be worked as ONE pass)
 MAX_PIXELS_PER_PASS = 1024 * 512 * 512
+
+
+class _BatchRunner:
+    """find_peptides over a stack of same-shaped fields: chunks of `per` fields are uploaded through pinned staging buffers,
+    streamed through a StreamPipeline (continuous batching of the LM fits: the slow fits of one chunk finish inside the round
+    launches of the next), and their peak records are copied back and turned into dicts by a worker thread while the GPU
+    works on the following chunks.  The object (pipeline workspaces, staging buffers) lives in the module cache between calls."""
+
+    def __init__(self, per, H, W):
+        torch = _engine._torch()
+        self.torch = torch
+        self.per, self.H, self.W = int(per), int(H), int(W)
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        self.pipe = _engine.StreamPipeline(self.per, H, W, depth=12, device=self.dev)
+        # four staging buffers: the stager runs at most two chunks ahead of the pipeline thread (queue of 2), so the buffer of
+        # chunk c is written again (chunk c + 4) only after the pipeline thread has recorded the upload event of chunk c
+        self.pin = [torch.empty((self.per, H, W), dtype=torch.int16).pin_memory() for _ in range(4)]
+        self.pin_ev = [None] * 4
+        self.lock = threading.Lock()
+
+    def close(self):
+        self.pipe.close()
+
+    def run(self, words, fmt, prm, r_2_threshold, radius, on_chunk=None, raw=False):
+        """words: uint16[n, H, W] (host).  -> list of n dicts / AssertionError instances.  on_chunk(first, dicts), if given, is
+        called (in the worker thread) as soon as the dicts of fields first .. first + len(dicts) - 1 exist.
+        raw=True: -> (peak records uint8[k, engine.PEAK_RECORD_BYTES] in field order, int32[n] peaks per field, -1 where the
+        re-key assertion fired) instead of dicts - the form the multi-GPU gather ships."""
+        import queue as _queue
+        import sys
+        torch, per = self.torch, self.per
+        n = len(words)
+        n_chunks = -(-n // per)
+        out = [None] * (n_chunks * per)
+        bufs = {}
+        pool = concurrent.futures.ThreadPoolExecutor(1)
+        futures = []
+        staged = _queue.Queue(maxsize=2)
+
+        def stage():        # (own thread) copies the chunks into the pinned staging buffers ahead of the pipeline
+            try:
+                for c in range(n_chunks):
+                    part = words[c * per:(c + 1) * per]
+                    i = c % 4
+                    if self.pin_ev[i] is not None:
+                        self.pin_ev[i].synchronize()        # the upload that last used this staging buffer
+                    host = self.pin[i].numpy().view(np.uint16)
+                    host[:len(part)] = part
+                    if len(part) < per:                     # the last chunk is filled up with copies of its last field
+                        host[len(part):] = part[-1]
+                    staged.put(i)
+            except BaseException as e:      # noqa: BLE001 - handed to the pipeline thread
+                staged.put(e)
+
+        def jobs():
+            for c in range(n_chunks):
+                i = staged.get()
+                if isinstance(i, BaseException):
+                    raise i
+                bufs[c] = self.pin[i].to(self.dev, non_blocking=True)
+                self.pin_ev[i] = torch.cuda.Event()
+                self.pin_ev[i].record()
+                yield bufs[c], prm
+
+        def materialise(c, rec, offs, nk, ev):
+            with torch.cuda.device(self.dev):
+                ev.synchronize()
+                rec_host = rec.cpu().numpy()
+                if not raw:
+                    rows, fit, sub = _engine.split_peak_records(rec_host, fmt)
+                nk = nk.cpu().numpy()
+                offs = offs.cpu().numpy()
+            if raw:
+                out[c] = (rec_host, np.where(nk < 0, nk, np.diff(offs)).astype(np.int32))
+                return
+            failed = set(int(f) for f in np.nonzero(nk < 0)[0])
+            dicts = _records_to_dicts(rows, fit, sub, offs, failed)
+            out[c * per:(c + 1) * per] = dicts
+            if on_chunk is not None:
+                on_chunk(c * per, dicts[:max(0, min(per, n - c * per))])
+
+        def on_done(c, eng, total):                         # (side stream current, the chunk consolidated on it)
+            rec, offs = eng.peak_records(bufs.pop(c))
+            nk = eng.nkeep[:per].clone()
+            ev = torch.cuda.Event()
+            ev.record()
+            futures.append(pool.submit(materialise, c, rec, offs, nk, ev))
+
+        with self.lock:
+            stager = threading.Thread(target=stage, daemon=True)
+            # (the pipeline thread needs the interpreter for a few calls per chunk; while the worker builds dicts it would
+            # wait a whole switch interval - 5 ms by default - for each of them)
+            interval = sys.getswitchinterval()
+            sys.setswitchinterval(1e-4)
+            try:
+                stager.start()
+                self.pipe.run(jobs(), on_done, r_2_threshold, radius, PY2_ROUND)
+            finally:
+                sys.setswitchinterval(interval)
+                while stager.is_alive():                    # (only after a failure: let it run out)
+                    try:
+                        staged.get(timeout=0.1)
+                    except _queue.Empty:
+                        pass
+                pool.shutdown(wait=True)
+        for f in futures:
+            f.result()                                      # re-raises what the worker raised
+        if raw:
+            # (the padding fields of the last chunk are cut off: their records sit at the end of that chunk's table)
+            counts = np.concatenate([out[c][1] for c in range(n_chunks)])[:n]
+            recs = []
+            for c in range(n_chunks):
+                k = int(np.maximum(out[c][1][:max(0, min(per, n - c * per))], 0).sum())
+                recs.append(out[c][0][:k])
+            return np.concatenate(recs) if recs else np.zeros((0, _engine.PEAK_RECORD_BYTES), np.uint8), counts
+        return out[:n]
 
 
 def find_peptides_batch(images, median_filter_size=5, correlation_matrix=default_correlation_matrix,
                         candidate_pixels=None, c_std=2, r_2_threshold=0.7, consolidation_radius=4,
-                        fit_type='gauss', N_iter=10**3, engine=None, errors='raise'):
+                        fit_type='gauss', N_iter=10**3, engine=None, errors='raise', on_chunk=None):
     """find_peptides over a stack uint16[n, H, W] -> list of n dicts.
 
-    One GPU pass for a stack of up to MAX_PIXELS_PER_PASS pixels; larger stacks are cut into equal chunks that are
-    streamed through engine.StreamPipeline (continuous batching of the LM fits).  errors='return' puts the
-    AssertionError of a field whose re-key collides (pflib.py:518) in that field's place instead of raising it."""
+    The stack is streamed through the GPU in chunks of about CHUNK_PIXELS pixels (engine.StreamPipeline: continuous
+    batching of the LM fits) by a _BatchRunner that stays alive between calls.  errors='return' puts the AssertionError of a
+    field whose re-key collides (pflib.py:518) in that field's place instead of raising it.  on_chunk(first_index, dicts)
+    is called as soon as a chunk's dicts exist (from a worker thread)."""
     if consolidation_radius < 2:
         raise ValueError("consolidation_radius must be at least 2")                # pflib.py:431-432
     if fit_type != 'gauss':
         raise NotImplementedError("fit_type='monte_carlo' draws from an unseeded RNG in the reference "
                                   "(pflib.py:117-177) and is not reproduced")
     # (candidate_pixels: "Not yet implemented" in the reference, pflib.py:374 - accepted and ignored there and here)
-    imgs, fmt = _engine.as_pixel_fields(images)            # integer dtypes, or float16 (fp16 pixel loads)
+    imgs, fmt = _engine.as_pixel_fields(images)            # integer dtypes, floats holding 16-bit values, or float16
     prm = _engine.detect_params(median_filter_size, correlation_matrix, c_std, fmt)
     if imgs.ndim != 3:
         raise ValueError("images must have shape (n, H, W)")
     n, H, W = imgs.shape
     if n == 0:
         return []
-    per = max(1, MAX_PIXELS_PER_PASS // (H * W))
-    if engine is not None or n <= per:
-        eng = engine or _engine.Engine(n, H, W)
+    if engine is not None:                                  # (a caller-owned Engine: one stand-alone pass)
         d_img = _engine.to_device_u16(imgs)
-        eng.run(d_img, prm, r_2_threshold, consolidation_radius, N.MODE_REF, PY2_ROUND)
-        out = _engine_dicts(eng, d_img, fmt)
+        engine.run(d_img, prm, r_2_threshold, consolidation_radius, N.MODE_REF, PY2_ROUND)
+        out = _engine_dicts(engine, d_img, fmt)
     else:
-        n_chunks = -(-n // per)
+        n_chunks = max(1, -(-(n * H * W) // CHUNK_PIXELS))
         per = -(-n // n_chunks)
-        pad = n_chunks * per - n                # the last chunk is filled up with copies of the last field
-        pipe = _engine.StreamPipeline(per, H, W, depth=min(8, n_chunks + 1))
-        out = [None] * (n_chunks * per)
-        bufs = {}
-
-        def jobs():
-            for c in range(n_chunks):
-                part = imgs[c * per:(c + 1) * per]
-                if len(part) < per:
-                    part = np.concatenate([part, np.repeat(part[-1:], pad, axis=0)])
-                bufs[c] = _engine.to_device_u16(part)
-                yield bufs[c], prm
-
-        def on_done(c, eng, total):
-            out[c * per:(c + 1) * per] = _engine_dicts(eng, bufs.pop(c), fmt)
-
-        try:
-            pipe.run(jobs(), on_done, r_2_threshold, consolidation_radius, PY2_ROUND)
-        finally:
-            pipe.close()
-        out = out[:n]
+        runner = _cached(("batch", _device_key(), per, H, W), lambda: _BatchRunner(per, H, W))
+        out = runner.run(imgs, fmt, prm, r_2_threshold, consolidation_radius, on_chunk)
     if errors == 'raise':
         for d in out:
             if isinstance(d, Exception):
                 raise d
     return out
+
+
+def find_peptides_records(images, median_filter_size=5, correlation_matrix=default_correlation_matrix, c_std=2,
+                          r_2_threshold=0.7, consolidation_radius=4, **unused):
+    """find_peptides over a stack, results as the byte tables the multi-GPU gather ships instead of dicts:
+    -> (records uint8[k, engine.PEAK_RECORD_BYTES] of all fields in order, int32[n] peaks per field (-1: the re-key
+    assertion of pflib.py:518 fired for that field), pixel format).  records_to_dicts turns them into find_peptides' dicts."""
+    if consolidation_radius < 2:
+        raise ValueError("consolidation_radius must be at least 2")
+    imgs, fmt = _engine.as_pixel_fields(images)
+    prm = _engine.detect_params(median_filter_size, correlation_matrix, c_std, fmt)
+    if imgs.ndim != 3:
+        raise ValueError("images must have shape (n, H, W)")
+    n, H, W = imgs.shape
+    if n == 0:
+        return np.zeros((0, _engine.PEAK_RECORD_BYTES), np.uint8), np.zeros(0, np.int32), fmt
+    n_chunks = max(1, -(-(n * H * W) // CHUNK_PIXELS))
+    per = -(-n // n_chunks)
+    runner = _cached(("batch", _device_key(), per, H, W), lambda: _BatchRunner(per, H, W))
+    rec, counts = runner.run(imgs, fmt, prm, r_2_threshold, consolidation_radius, raw=True)
+    return rec, counts, fmt
+
+
+def records_to_dicts(records, counts, pixel_format=N.PIXELS_U16):
+    """The inverse packaging of find_peptides_records: -> list of dicts (AssertionError instances for failed fields)."""
+    rows, fit, sub = _engine.split_peak_records(records, pixel_format)
+    counts = np.asarray(counts).reshape(-1)
+    failed = set(int(k) for k in np.nonzero(counts < 0)[0])
+    offs = np.concatenate([[0], np.cumsum(np.maximum(counts, 0))])
+    return _records_to_dicts(rows, fit, sub, offs, failed)
+
+
+def count_candidates(images, median_filter_size=5, correlation_matrix=default_correlation_matrix, c_std=2, **unused):
+    """Number of PSF candidates of every field of a stack (one detection pass, no fits): the weights of the
+    longest-processing-time partition (pflib.py:1043-1054)."""
+    imgs, fmt = _engine.as_pixel_fields(images)
+    prm = _engine.detect_params(median_filter_size, correlation_matrix, c_std, fmt)
+    if imgs.ndim != 3:
+        raise ValueError("images must have shape (n, H, W)")
+    n, H, W = imgs.shape
+    if n == 0:
+        return np.zeros(0, np.int64)
+    eng = _cached(("count", _device_key(), n, H, W), lambda: _engine.Engine(n, H, W, fit_workspace=False))
+    with _CACHE_LOCK:
+        eng.detect(_engine.to_device_u16(imgs), prm)
+        return eng.counts[:n].cpu().numpy().astype(np.int64)
 
 
 def find_peptides(image, median_filter_size=5, correlation_matrix=default_correlation_matrix,
@@ -237,33 +449,32 @@ def _output_path(image_path, timestamp_epoch, output_path, suffix):
     return output_path
 
 
-class _Py2Pickler(pickle._Pickler):
-    """Protocol-0 pickler whose numpy globals carry the module paths of numpy 1.x (`numpy.core.multiarray`), which
-    numpy 2 still resolves: the files are read back by the reference's Python 2 (flexlibrary.py:541-547), whose
-    numpy has no `numpy._core`."""
+_PICKLE_LOCK = threading.Lock()
+_NUMPY2_MODULES = ("numpy._core", "numpy._core.multiarray", "numpy._core.numeric", "numpy._core._multiarray_umath")
 
-    def save_global(self, obj, name=None):
-        mod = getattr(obj, "__module__", None) or ""
-        if mod.startswith("numpy._core"):
-            name = name or getattr(obj, "__qualname__", None) or obj.__name__
-            self.write(pickle.GLOBAL + ("numpy.core" + mod[len("numpy._core"):]).encode("ascii") + b"\n" +
-                       name.encode("ascii") + b"\n")
-            self.memoize(obj)
-            return
-        pickle._Pickler.save_global(self, obj, name)
 
-    dispatch = dict(pickle._Pickler.dispatch)
-    import types as _types
-    dispatch[_types.FunctionType] = save_global
-    dispatch[_types.BuiltinFunctionType] = save_global
-    del _types
+def _py2_pickle_bytes(obj):
+    """Protocol-0 pickle of `obj` whose numpy globals carry the module paths of numpy 1.x (`numpy.core.multiarray`), which
+    numpy 2 still resolves: the files are read back by the reference's Python 2 (flexlibrary.py:541-547), whose numpy has no
+    `numpy._core`.  The C pickler does the work; it renames modules for protocols < 3 through the tables of `_compat_pickle`
+    (the mechanism that writes `__builtin__` for `builtins`), which get the numpy entries for the duration of the call."""
+    import _compat_pickle
+    with _PICKLE_LOCK:
+        added = [m for m in _NUMPY2_MODULES if m not in _compat_pickle.REVERSE_IMPORT_MAPPING]
+        for m in added:
+            _compat_pickle.REVERSE_IMPORT_MAPPING[m] = "numpy.core" + m[len("numpy._core"):]
+        try:
+            return pickle.dumps(obj, protocol=0, fix_imports=True)
+        finally:
+            for m in added:
+                del _compat_pickle.REVERSE_IMPORT_MAPPING[m]
 
 
 def save_psfs_pkl(psfs, image_path=None, timestamp_epoch=None, output_path=None):
     """Pickle the PSF dict with protocol 0, as the reference's cPickle.dump does (pflib.py:594-636)."""
     output_path = _output_path(image_path, timestamp_epoch, output_path, '.pkl')
     with open(output_path, 'wb') as f:
-        _Py2Pickler(f, protocol=0).dump(psfs)
+        f.write(_py2_pickle_bytes(psfs))
     return output_path
 
 
@@ -337,6 +548,170 @@ def save_psfs_png(psfs, image_path=None, timestamp_epoch=None, output_path=None,
     return None
 
 
+#: image_batch / _candidate_counts hold at most about this many pixels of one image shape in host memory before they are
+#: worked off (fitted, saved, dropped): a directory tree of any size is processed in bounded memory, results are on disk as
+#: soon as their window is done
+WINDOW_PIXELS = 8 * CHUNK_PIXELS
+
+
+# ---- host-side workers for the file layer ------------------------------------------------------------------------------
+# Per image the GPU needs a fraction of a millisecond; converting / decoding the image and writing its protocol-0 pickle
+# (1 MB of text) and CSV take ~100 ms of host time.  The reference runs whole images in worker processes
+# (multiprocessing.Pool, pflib.py:1082-1099); here the GPU work stays in this process and the workers do the file work:
+# read_image before, save_psfs_* after.  They are spawned (never forked: this process may have initialised the GPU) and
+# import nothing that touches the GPU.
+IO_WORKERS = None               # None: min(8, half the cores); 0: everything in this process
+_IO_POOL = {"pool": None, "n": 0}
+IO_POOL_MIN_IMAGES = 16         # lists shorter than this are not worth starting the workers for
+
+
+class _IoPool:
+    """n worker processes (`python -m fluorosequencingimageanalysis_amd._io_worker`), each served by one thread of a thread
+    pool: submit(name, *args) -> Future of pflib._read_job / _save_job run in a worker."""
+
+    def __init__(self, n):
+        self.n = int(n)
+        self.threads = concurrent.futures.ThreadPoolExecutor(self.n)
+        self.local = threading.local()
+        self.procs = []
+        self.lock = threading.Lock()
+
+    def _worker(self):
+        w = getattr(self.local, "proc", None)
+        if w is None or w.poll() is not None:
+            import subprocess
+            import sys
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            env = dict(os.environ)
+            env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+            w = subprocess.Popen([sys.executable, "-m", "fluorosequencingimageanalysis_amd._io_worker"], stdin=subprocess.PIPE,
+                                 stdout=subprocess.PIPE, env=env)
+            self.local.proc = w
+            with self.lock:
+                self.procs.append(w)
+        return w
+
+    def _call(self, name, args):
+        import struct
+        w = self._worker()
+        blob = pickle.dumps((name, args), protocol=pickle.HIGHEST_PROTOCOL)
+        w.stdin.write(struct.pack("<q", len(blob)))
+        w.stdin.write(blob)
+        w.stdin.flush()
+        head = w.stdout.read(8)
+        if len(head) < 8:
+            raise RuntimeError("an I/O worker process died")
+        res = pickle.loads(w.stdout.read(struct.unpack("<q", head)[0]))
+        if isinstance(res, tuple) and len(res) == 2 and res[0] == "__worker_error__":
+            raise RuntimeError(res[1])
+        return res
+
+    def submit(self, name, *args):
+        return self.threads.submit(self._call, name, args)
+
+    def shutdown(self):
+        self.threads.shutdown(wait=True)
+        for w in self.procs:
+            try:
+                w.stdin.close()
+                w.wait(timeout=10)
+            except Exception:       # noqa: BLE001
+                w.kill()
+
+
+def _io_pool(n_images, num_processes=None):
+    n = IO_WORKERS if IO_WORKERS is not None else min(8, max(1, (os.cpu_count() or 2) // 2))
+    if num_processes is not None:
+        n = int(num_processes)
+    if n <= 0 or n_images < IO_POOL_MIN_IMAGES:
+        return None
+    with _CACHE_LOCK:
+        if _IO_POOL["pool"] is None or _IO_POOL["n"] != n:
+            if _IO_POOL["pool"] is not None:
+                _IO_POOL["pool"].shutdown()
+            _IO_POOL["pool"] = _IoPool(n)
+            _IO_POOL["n"] = n
+        return _IO_POOL["pool"]
+
+
+def shutdown_io_workers():
+    with _CACHE_LOCK:
+        if _IO_POOL["pool"] is not None:
+            _IO_POOL["pool"].shutdown()
+            _IO_POOL["pool"] = None
+
+
+atexit.register(shutdown_io_workers)
+
+
+def _portable_error(e):
+    """An exception that survives the trip between processes (its class may not pickle)."""
+    try:
+        pickle.loads(pickle.dumps(e))
+        return e
+    except Exception:           # noqa: BLE001
+        return RuntimeError("%s: %s" % (type(e).__name__, e))
+
+
+def _read_job(ap):
+    """(worker process or inline) -> (path, converted path, uint16 array, None) or (path, None, None, exception)."""
+    try:
+        converted, img = read_image(ap)
+        a = _engine.as_u16_fields(img)
+        if a.ndim != 2:
+            raise ValueError("image must be two-dimensional")
+        return ap, converted, a, None
+    except Exception as e:      # noqa: BLE001 - reported per image, like the reference (pflib.py:960-964)
+        return ap, None, None, _portable_error(e)
+
+
+def _save_job(psfs, converted, timestamp_epoch):
+    """(worker process or inline) -> ((pkl, csv, png) paths, None) or (None, exception)."""
+    try:
+        return (save_psfs_pkl(psfs, image_path=converted, timestamp_epoch=timestamp_epoch),
+                save_psfs_csv(psfs, image_path=converted, timestamp_epoch=timestamp_epoch),
+                save_psfs_png(psfs, image_path=converted, timestamp_epoch=timestamp_epoch)), None
+    except Exception as e:      # noqa: BLE001
+        return None, _portable_error(e)
+
+
+def _read_all(image_paths, pool):
+    """read_image for every path, in order; with a pool a bounded number of reads is in flight ahead of the consumer."""
+    if pool is None:
+        for ap in image_paths:
+            yield _read_job(ap)
+        return
+    ahead = collections.deque()
+    it = iter(image_paths)
+    limit = 4 * _IO_POOL["n"]
+    while True:
+        while len(ahead) < limit:
+            try:
+                ahead.append(pool.submit("read", next(it)))
+            except StopIteration:
+                break
+        if not ahead:
+            return
+        yield ahead.popleft().result()
+
+
+def _windows(image_paths, on_unreadable, pool=None):
+    """Read the images of a list in order and yield them in windows of same-shaped images, each window at most
+    WINDOW_PIXELS pixels: (shape, [(path, converted_path, uint16 array), ...]).  An image that cannot be read, or is not a
+    2-D image with 16-bit values, is reported through on_unreadable(path, exception) and skipped."""
+    pending = {}
+    for ap, converted, a, err in _read_all(image_paths, pool):
+        if err is not None:
+            on_unreadable(ap, err)
+            continue
+        group = pending.setdefault(a.shape, [])
+        group.append((ap, converted, a))
+        if len(group) * a.size >= WINDOW_PIXELS:
+            yield a.shape, pending.pop(a.shape)
+    for shape in list(pending):
+        yield shape, pending.pop(shape)
+
+
 def _fit_image_groups(images, find_peptides_parameters):
     """find_peptides for a list of 2-D images of any shapes: same-shaped images go through the GPU together
     (find_peptides_batch); -> list of dicts, with the exception an image raised in its place."""
@@ -362,32 +737,35 @@ def _fit_image_groups(images, find_peptides_parameters):
 
 def _candidate_counts(image_paths, detect_parameters=None):
     """Number of PSF candidates of every image of a list (None where the image cannot be read) - what
-    pflib.parallel_image_batch balances its workers by (pflib.py:1043-1050).  Same-shaped images share a GPU pass."""
+    pflib.parallel_image_batch balances its workers by (pflib.py:1043-1050).  Same-shaped images share a GPU pass; the list
+    is worked through in bounded windows (_windows)."""
     log = logging.getLogger()
     prm = _engine.detect_params(**{"median_filter_size": 5, "correlation_matrix": default_correlation_matrix, "c_std": 2,
                                    **(detect_parameters or {})})
-    out = [None] * len(image_paths)
-    groups = {}
+    index = {}
     for i, p in enumerate(image_paths):
-        try:
-            a = _engine.as_u16_fields(read_image(p)[1])
-            if a.ndim != 2:
-                raise ValueError("image must be two-dimensional")
-            groups.setdefault(a.shape, []).append((i, a))
-        except Exception as e:      # noqa: BLE001 - logged and skipped like pflib.py:1044-1048
-            log.exception(e, exc_info=True)
-    for (H, W), members in groups.items():
-        eng = _engine.Engine(len(members), H, W, fit_workspace=False)
-        eng.detect(_engine.to_device_u16(np.stack([a for _, a in members])), prm)
-        counts = eng.counts.cpu().numpy()
-        for k, (i, _) in enumerate(members):
-            out[i] = int(counts[k])
+        index.setdefault(p, []).append(i)
+    out = [None] * len(image_paths)
+
+    def unreadable(path, e):        # logged and skipped like pflib.py:1044-1048
+        log.exception(e, exc_info=True)
+
+    for (H, W), members in _windows(list(dict.fromkeys(image_paths)), unreadable):
+        eng = _cached(("count", _device_key(), len(members), H, W), lambda: _engine.Engine(len(members), H, W, fit_workspace=False))
+        with _CACHE_LOCK:
+            eng.detect(_engine.to_device_u16(np.stack([a for _, _, a in members])), prm)
+            counts = eng.counts.cpu().numpy()
+        for k, (p, _, _) in enumerate(members):
+            for i in index[p]:
+                out[i] = int(counts[k])
     return out
 
 
-def image_batch(image_paths, find_peptides_parameters=None, timestamp_epoch=None):
+def image_batch(image_paths, find_peptides_parameters=None, timestamp_epoch=None, num_processes=None):
     """Find PSFs in every image of a list and save them as pickle and CSV; per-image failures are logged and
-    skipped (pflib.py:883-996).  Same-shaped images share one GPU pass.
+    skipped (pflib.py:883-996).  Same-shaped images share GPU passes; the list is worked through in windows of bounded size
+    (_windows), every window's files being written before the next one is fitted; reading / converting the images and writing
+    the files is done by host worker processes (num_processes of them; None: IO_WORKERS) while this process drives the GPU.
     Returns {absolute image path: (converted image path, pkl path, csv path, png path)} (png: save_psfs_png)."""
     log = logging.getLogger()
     if timestamp_epoch is None:
@@ -395,29 +773,39 @@ def image_batch(image_paths, find_peptides_parameters=None, timestamp_epoch=None
     paths = list(dict.fromkeys(os.path.abspath(p) for p in image_paths))       # absolute, duplicates dropped (:947-949)
     if find_peptides_parameters is None:
         find_peptides_parameters = {}
-    read = []
-    for ap in paths:
+    pool = _io_pool(len(paths), num_processes)
+    done, saving = {}, collections.deque()
+
+    def unreadable(path, e):        # the reference swallows and logs every per-image failure (:960-964)
+        log.error("cannot read %s", path, exc_info=(type(e), e, e.__traceback__))
+
+    def reap(keep):
+        while len(saving) > keep:
+            ap, converted, fut = saving.popleft()
+            files, err = fut.result() if pool is not None else fut
+            if err is not None:
+                log.error("cannot save the PSFs of %s", ap, exc_info=(type(err), err, err.__traceback__))
+            else:
+                done.setdefault(ap, (converted,) + tuple(files))
+
+    for shape, members in _windows(paths, unreadable, pool):
         try:
-            converted, img = read_image(ap)
-        except Exception as e:      # noqa: BLE001 - the reference swallows and logs every per-image failure (:960-964)
-            log.exception(e, exc_info=True)
-            continue
-        read.append((ap, converted, img))
-    results = _fit_image_groups([img for _, _, img in read], find_peptides_parameters)
-    processed = {}
-    for (ap, converted, img), psfs in zip(read, results):
-        if isinstance(psfs, Exception):
-            log.error("find_peptides failed for %s", ap, exc_info=(type(psfs), psfs, psfs.__traceback__))
-            continue
-        try:
-            pkl = save_psfs_pkl(psfs, image_path=converted, timestamp_epoch=timestamp_epoch)
-            tab = save_psfs_csv(psfs, image_path=converted, timestamp_epoch=timestamp_epoch)
-            png = save_psfs_png(psfs, image_path=converted, timestamp_epoch=timestamp_epoch)
-        except Exception as e:      # noqa: BLE001
-            log.exception(e, exc_info=True)
-            continue
-        processed.setdefault(ap, (converted, pkl, tab, png))
-    return processed
+            res = find_peptides_batch(np.stack([a for _, _, a in members]), errors='return', **find_peptides_parameters)
+        except Exception as e:      # noqa: BLE001 - parameter errors etc. hit every image of the window
+            res = [e] * len(members)
+        for (ap, converted, _), psfs in zip(members, res):
+            if isinstance(psfs, Exception):
+                log.error("find_peptides failed for %s", ap, exc_info=(type(psfs), psfs, psfs.__traceback__))
+                continue
+            if pool is not None:
+                saving.append((ap, converted, pool.submit("save", psfs, converted, timestamp_epoch)))
+                reap(8 * _IO_POOL["n"])
+            else:
+                saving.append((ap, converted, _save_job(psfs, converted, timestamp_epoch)))
+                reap(0)
+        del res, members
+    reap(0)
+    return {ap: done[ap] for ap in paths if ap in done}
 
 
 def parallel_image_batch(image_paths, find_peptides_parameters=None, timestamp_epoch=None, num_processes=None):
@@ -427,10 +815,11 @@ def parallel_image_batch(image_paths, find_peptides_parameters=None, timestamp_e
     the ranks of the torch.distributed job this process belongs to (one process per GPU, `torchrun`): images are
     balanced over them with the same longest-processing-time rule and every rank's results are merged on all ranks
     (fluorosequencingimageanalysis_amd.distributed.image_batch_sharded).  Without a process group one GPU handles all
-    images.  num_processes is validated like the reference's (:1060-1061) and otherwise ignored."""
+    images.  num_processes is validated like the reference's (:1060-1061); it sets the number of host worker processes that
+    read / convert the images and write the result files (image_batch)."""
     if num_processes is not None and (num_processes < 1 or round(num_processes) != num_processes):
         raise ValueError("Number of processes must be an integer >= 1")
     from . import distributed as _dist
     if _dist.world_size() > 1:
         return _dist.image_batch_sharded(image_paths, find_peptides_parameters, timestamp_epoch)
-    return image_batch(image_paths, find_peptides_parameters, timestamp_epoch)
+    return image_batch(image_paths, find_peptides_parameters, timestamp_epoch, num_processes)

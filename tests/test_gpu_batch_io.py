@@ -78,12 +78,12 @@ def test_cli_over_a_directory_of_tiffs(env, tmp_path):
 
 
 def test_chunked_batch_equals_one_pass(env, monkeypatch):
-    """A stack larger than MAX_PIXELS_PER_PASS goes through engine.StreamPipeline in chunks (the last one padded):
+    """A stack larger than CHUNK_PIXELS goes through engine.StreamPipeline in chunks (the last one padded):
     same dicts as one pass."""
     cli, pflib, synth, O = env
     imgs = np.stack([synth.make_field(600 + i, (96, 96), 8 + i) for i in range(11)])
     one = pflib.find_peptides_batch(imgs)
-    monkeypatch.setattr(pflib, "MAX_PIXELS_PER_PASS", 3 * 96 * 96)
+    monkeypatch.setattr(pflib, "CHUNK_PIXELS", 3 * 96 * 96)
     many = pflib.find_peptides_batch(imgs)
     assert len(one) == len(many) == 11
     for a, b in zip(one, many):

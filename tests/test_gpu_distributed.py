@@ -85,3 +85,83 @@ def test_sharded_world1_is_batch():
     from fluorosequencingimageanalysis_amd import distributed as D, pflib
     imgs = _fields()[:3]
     _same_dicts(D.find_peptides_sharded(imgs), pflib.find_peptides_batch(imgs))
+
+
+# ---- the parallel FILE path under two ranks: basic_image_script / pflib.parallel_image_batch (pflib.py:1043-1111) ----------
+def _make_tiffs(d):
+    """10 ragged 16-bit TIFFs of two shapes (5 .. 60 spots: very different candidate counts) and one unreadable file."""
+    from PIL import Image
+    from fluorosequencingimageanalysis_amd import synth
+    os.makedirs(os.path.join(d, "sub"), exist_ok=True)
+    paths = []
+    for i, spots in enumerate((5, 60, 10, 40, 25, 8, 50, 30, 15, 35)):
+        img = synth.make_field(500 + i, (96, 96) if i % 3 else (64, 80), spots)
+        p = os.path.join(d, "sub" if i % 4 == 0 else "", "im%02d.tif" % i)
+        Image.fromarray(img).save(p, format="TIFF")
+        paths.append(p)
+    open(os.path.join(d, "broken.tif"), "wb").write(b"II*\x00garbage")
+    return paths
+
+
+def _cli_worker(rank, world, port, q, d):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", FSQ_DIST_BACKEND="gloo")
+    import torch
+    torch.cuda.set_device(0)
+    from fluorosequencingimageanalysis_amd import basic_image_script as cli, pflib
+    seen = {}
+    real = pflib.image_batch
+
+    def spy(paths, *a, **k):            # which images this rank was dealt
+        seen["mine"] = list(paths)
+        return real(paths, *a, **k)
+    pflib.image_batch = spy
+    res = cli.main(["--parameters", "{'c_std': 2}", "-n", "2", "-L", os.path.join(d, "log.txt"), d])
+    q.put((rank, res, seen.get("mine", [])))
+
+
+def test_cli_two_ranks_equal_one_rank(tmp_path):
+    """python -m ... basic_image_script under two ranks (fresh processes on the one GPU, gloo): the merged result dict, every
+    image's pickle / CSV and the longest-processing-time assignment equal what a single rank produces; the unreadable file is
+    logged and skipped; both ranks return the same dict."""
+    import pickle
+    import warnings
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import torch.multiprocessing as mp
+    from fluorosequencingimageanalysis_amd import basic_image_script as cli, distributed as D, pflib
+    d1, d2 = str(tmp_path / "one"), str(tmp_path / "two")
+    _make_tiffs(d1)
+    paths2 = _make_tiffs(d2)
+    one = cli.main(["--parameters", "{'c_std': 2}", "-L", os.path.join(d1, "log.txt"), d1])
+    assert len(one) == 10
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cli_worker, args=(r, 2, port, q, d2)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r, (res, mine)) for r, res, mine in (q.get(timeout=600) for _ in range(2)))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[0][0] == got[1][0]
+    two = got[0][0]
+    assert sorted(os.path.relpath(p, d2) for p in two) == sorted(os.path.relpath(p, d1) for p in one)
+    # every rank got a share, the shares are disjoint, cover the readable images and follow the LPT rule on the counts
+    mine0, mine1 = set(got[0][1]), set(got[1][1])
+    assert mine0 and mine1 and not (mine0 & mine1) and (mine0 | mine1) == set(two)
+    listed = cli.find_target_images([d2])
+    counts = pflib._candidate_counts(listed)
+    assign = D.lpt_assignment(listed, counts, 2)
+    assert {p for p, r in assign.items() if r == 0} == mine0 and {p for p, r in assign.items() if r == 1} == mine1
+    assert "broken.tif" in open(os.path.join(d2, "log.txt")).read() + open(os.path.join(d2, "log.txt.rank1")).read()
+    for p2, v2 in two.items():
+        v1 = one[os.path.join(d1, os.path.relpath(p2, d2))]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            a, b = pickle.load(open(v1[1], "rb")), pickle.load(open(v2[1], "rb"))
+        _same_dicts([a], [b])
+        t1, t2 = open(v1[2], newline="").read().split("\r\n"), open(v2[2], newline="").read().split("\r\n")
+        assert [x.split("\t")[1:] for x in t1] == [x.split("\t")[1:] for x in t2] and len(t1) == len(a) + 2

@@ -72,10 +72,14 @@ def test_parameter_validation_without_gpu():
     assert p.ksz == 5 and p.K[12] == 30742 and p.K[0] == -5935
     with pytest.raises(ValueError):
         pflib.find_peptides(np.zeros((16, 16), np.uint16), consolidation_radius=1)
-    with pytest.raises(NotImplementedError):
-        engine.as_u16_fields(np.zeros((4, 4), float))
-    with pytest.raises(NotImplementedError):
-        engine.as_u16_fields(np.array([[70000]]))
+    # floating-point pixels are truncated toward zero like the reference's image.astype(np.int64) (pflib.py:241, 443)
+    got = engine.as_u16_fields(np.array([[0.0, 1.9, 65535.99], [2.5, 3.0, 100.2]]))
+    assert got.dtype == np.uint16 and got.tolist() == [[0, 1, 65535], [2, 3, 100]]
+    assert engine.as_u16_fields(np.array([[7, 9]], np.int32)).tolist() == [[7, 9]]
+    for bad in (np.array([[70000]]), np.array([[-1]]), np.array([[65536.0]]), np.array([[-0.5 - 1]]), np.array([[np.nan]]),
+                np.array([[np.inf]]), np.array([[1 + 2j]])):
+        with pytest.raises(NotImplementedError):
+            engine.as_u16_fields(bad)
     assert pflib.illumina_s_n(np.arange(25).reshape(5, 5)) == (24 - np.mean([0, 1, 2, 3, 4, 20, 21, 22, 23, 24, 5, 9, 10, 14, 15, 19])) / np.std([0, 1, 2, 3, 4, 20, 21, 22, 23, 24, 5, 9, 10, 14, 15, 19])
     with pytest.raises(ValueError):
         pflib.illumina_s_n(np.zeros((4, 5)))
