@@ -234,6 +234,48 @@ class Experiment(object):
     """The static tracking helpers of the reference's Experiment class."""
 
     @staticmethod
+    def easy_load_processed_image(image_filepath, psf_pkl_filepath=None, load_psfs=True):
+        """Load a processed image and the PSF pickle pflib wrote for it into an Image with its Spots.
+        Reference flexlibrary.py:516-564 (the resume mechanism of the experiment scripts: an image that has a
+        `<image>*_psfs_*.pkl` next to it is not fitted again, basic_experiment_script.py:243-247, 377-399).
+
+        image_filepath: path of the PNG image; psf_pkl_filepath: its pickle, or None to take the last of
+        sorted(glob(image_filepath + '*_psfs_*.pkl')) - the file names end in the base-36 time stamp of
+        pflib._psfs_filename, so that is the most recent one; load_psfs=False: the Image gets no Spots.
+        Returns (Image, number of PSFs whose Spot could not be made): every PSF becomes a Spot at the Python-2-rounded
+        dict key with size fit_img.shape[0]; a PSF for which Spot.__init__ raises is logged and counted."""
+        import glob
+        import logging
+        import pickle
+        from PIL import Image as _PILImage
+        logger = logging.getLogger(__name__)
+        with _PILImage.open(image_filepath) as f:
+            image = np.array(f)
+        image_object = Image(image=image, metadata={'filepath': image_filepath}, spots=None)
+        discarded_spots = 0
+        if load_psfs:
+            if psf_pkl_filepath is None:
+                pkl_files = sorted(glob.glob(image_filepath + '*_psfs_*.pkl'))
+                if len(pkl_files) == 0:
+                    raise ValueError("For image_filepath = " + image_filepath + " psf_pkl_filepath passed as None when " +
+                                     "no pkl files available.")
+                psf_pkl_filepath = pkl_files[-1]
+            with open(psf_pkl_filepath, 'rb') as f:
+                psfs = pickle.load(f, encoding='latin1')        # (latin1: files written by the reference's Python 2)
+            spot_objects = []
+            for (h, w), gaussian_fit in psfs.items():
+                fit_img = gaussian_fit[8]
+                try:
+                    spot_objects.append(Spot(parent_Image=image_object, h=int(_py2_round(h)), w=int(_py2_round(w)),
+                                             size=fit_img.shape[0], gaussian_fit=gaussian_fit))
+                except Exception as e:      # noqa: BLE001 - as the reference: logged, counted, skipped
+                    logger.info("flexlibrary.easy_load_processed_image: Ignoring Spot due to Spot.__init__ exception.")
+                    logger.exception(e, exc_info=True)
+                    discarded_spots += 1
+            image_object.spots = spot_objects
+        return image_object, discarded_spots
+
+    @staticmethod
     def luminosity_centroid_particle_tracking(frames, initial_spots, search_radius=3, s_n_cutoff=3.0, offsets=None):
         """Follow Spots through frames by the centroid of pixel luminosity.  flexlibrary.py:1262-1317.
         frames: Images (objects with `.image`) of one shape; initial_spots: Spots of frames[0] (size 5).

@@ -9,7 +9,7 @@ fluorosequencingimageanalysis_amd/synth.py.  The .npz files hold DATA only
 
 Usage (about 4 minutes on 8 cores):
   NPY_DISABLE_CPU_FEATURES="AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL AVX512_SPR" \
-      python oracle/gen_golden.py [--only fields|reg|kat|phot|degen|textbook|io|track|centroid]
+      python oracle/gen_golden.py [--only fields|reg|kat|phot|degen|textbook|io|loader|track|centroid]
 
 Golden sets: G1 per-ROI fits, G2 candidate lists, G3 full
 find_peptides tables, G4 phase_correlate tuples, G5 known-answer tests.
@@ -491,6 +491,53 @@ def gen_io():
     print("io fixtures:", meta["csv_path"], meta["n_psfs"], flush=True)
 
 
+def loader_inputs(psfs_full):
+    """The two PSF dicts of the easy_load_processed_image fixture (shared with tests/test_flexlibrary_loader.py, which rebuilds
+    them from the committed field fixture): an older complete one, and a newer one with half the PSFs plus three crafted
+    entries that exercise Spot.__init__'s bounds logic (flexlibrary.py:100-112)."""
+    items = list(psfs_full.items())
+    newer = dict(items[:len(items) // 2])
+    sub, fit = np.zeros((5, 5), np.int64), np.zeros((5, 5))
+    mk = lambda h0, w0: (np.float64(h0), np.float64(w0), np.float64(100.), np.float64(500.), np.float64(1.), np.float64(1.),  # noqa: E731
+                         np.float64(0.), sub, fit, 1.0, np.float64(0.9), np.float64(5.))
+    newer[(0, 50)] = mk(0.4, 50.2)          # square off the top edge, fitted centre too close to it: rejected
+    newer[(1, 30)] = mk(2.2, 30.1)          # square off the top edge, fitted centre inside the margin: accepted
+    newer[(40, 95)] = mk(40.3, 200.0)       # square off the right edge; the `and`/`or` precedence of :104-111 lets it pass
+    return dict(items), newer
+
+
+def gen_loader():
+    """Experiment.easy_load_processed_image (flexlibrary.py:516-564) on files the reference's own save_psfs_pkl wrote: the
+    latest `<image>*_psfs_*.pkl` wins, every PSF becomes a Spot of size fit_img.shape[0] unless Spot.__init__ raises."""
+    import json
+    import tempfile
+    from PIL import Image as PILImage
+    R = _ref()
+    from refload import load_flexlibrary
+    load_flexlibrary(R)
+    R.fl.imread = lambda p: np.array(PILImage.open(p))
+    spec = FIELDS["f5_small_96"]
+    img = build_field(spec)
+    older, newer = loader_inputs(R.pf.find_peptides(img))
+    d = tempfile.mkdtemp()
+    png = os.path.join(d, "f5_small_96.tif.png")
+    PILImage.fromarray(img).save(png)
+    R.pf.save_psfs_pkl(older, image_path=png, timestamp_epoch=1450000000.4)
+    R.pf.save_psfs_pkl(newer, image_path=png, timestamp_epoch=1450000500.0)
+    # (the reference opens the pickle in Python 2's text mode; under Python 3 it has to be binary)
+    im, discarded = R.fl.Experiment.easy_load_processed_image(png)
+    im_old, disc_old = R.fl.Experiment.easy_load_processed_image(png, psf_pkl_filepath=R.pf._psfs_filename(png, 1450000000.4, ".pkl"))
+    im_none, disc_none = R.fl.Experiment.easy_load_processed_image(png, load_psfs=False)
+    out = {"epochs": [1450000000.4, 1450000500.0],
+           "latest": {"spots": [[int(s.h), int(s.w), int(s.size)] for s in im.spots], "discarded": int(discarded),
+                      "fit_h0": [float(s.gaussian_fit[0]) for s in im.spots]},
+           "older": {"spots": [[int(s.h), int(s.w), int(s.size)] for s in im_old.spots], "discarded": int(disc_old)},
+           "no_psfs": {"spots": len(im_none.spots), "discarded": int(disc_none)},
+           "image_shape": list(im.image.shape), "filepath_is_metadata": im.metadata == {"filepath": png}}
+    json.dump(out, open(os.path.join(GOLD, "loader_f5_small_96.json"), "w"), indent=1)
+    print("loader fixture:", len(out["latest"]["spots"]), "spots,", out["latest"]["discarded"], "discarded;", len(out["older"]["spots"]), "in the older file", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -510,6 +557,8 @@ def main():
         gen_tracking()
     if a.only in ("", "centroid"):
         gen_centroid()
+    if a.only in ("", "loader"):
+        gen_loader()
     if a.only in ("", "io"):
         gen_io()
     if a.only in ("", "degen"):

@@ -109,6 +109,8 @@ def load_flexlibrary(ref=None):
     # Python-2 round() (half away from zero) for the bin coordinates of the tracking code (flexlibrary.py:850, 880)
     # (Python 2: `/` between ints is floor division - Spot's (size - 1) / 2 radius feeds numpy slices)
     ref.fl = load("flexlibrary", "flexlibrary.py",
-                  [("(self.size - 1) / 2", "(self.size - 1) // 2"), ("(size - 1) / 2", "(size - 1) // 2")],
+                  [("(self.size - 1) / 2", "(self.size - 1) // 2"), ("(size - 1) / 2", "(size - 1) // 2"),
+                   # (Python 3: a pickle is read from a binary file - the reference opens it in Python 2's text mode, :547)
+                   ("pickle.load(open(psf_pkl_filepath))", "pickle.load(open(psf_pkl_filepath, 'rb'))")],
                   inject={"round": lambda x: libm.round(float(x))})
     return ref

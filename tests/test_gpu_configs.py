@@ -2,10 +2,12 @@
 config 3 (cycle stack: registration + per-cycle fitting), config 5 (a 2 048x2 048 high-density field), config 2 at
 its full size through a size-independent property (1 024 copies of a golden field must each reproduce the reference's
 table for that field), and the two-lane pipeline bench.py uses."""
+import os
+
 import numpy as np
 import pytest
 
-from _util import bits_equal, load_field
+from _util import GOLD, bits_equal, load_field
 
 pytestmark = pytest.mark.gpu
 
@@ -55,6 +57,57 @@ def test_config3_cycle_stack_registration_and_fitting(env):
         _same_table(out[idx], rows, fits, keep, key)
     # dropout: later cycles hold fewer spots
     assert len(out[n_cycles - 1]) < len(out[0])
+
+
+def test_config3_full_size_stack(env):
+    """configs[2] at its size, as ONE workload: a 4-channel x 8-cycle stack of 512x512 frames.  Channel 0 registers the cycles
+    (flexlibrary.py:1717-1741; the first five steps are the reference's own phase_correlate outputs behind the cycle512_* /
+    stack512 goldens, the rest the oracle's), all 32 frames are fitted in one find_peptides_batch (two checked in full
+    against the oracle), and the Spots of channel 0 are tracked (basic_experiment_script.py:424-471): the six-frame prefix
+    reproduces the reference's traces (tests/golden/tracking.npz, stack512), the whole stack the oracle tracker's."""
+    torch, N, engine, pflib, pc, synth, O = env
+    from fluorosequencingimageanalysis_amd import flexlibrary as fl
+    from test_tracking import load_cases
+    n_cycles, shape = 8, (512, 512)
+    stacks = [synth.make_cycle_stack(3 + ch, n_cycles=n_cycles, shape=shape, n_spots=500)[0] for ch in range(4)]
+    frames0 = stacks[0]
+    gold = np.load(os.path.join(GOLD, "registration.npz"))
+    for k in range(1, 5):                                   # the very frames the reference registered
+        assert np.array_equal(frames0[k - 1], gold["ref_cycle512_%d" % k]) and np.array_equal(frames0[k], gold["reg_cycle512_%d" % k])
+    name, ref_hw, ref_offsets, _, radius, spot_radius, ref_traces, ref_discarded = next(c for c in load_cases() if c[0] == "stack512")
+    # fitting: all 32 frames in one call
+    allf = np.concatenate(stacks)
+    out = pflib.find_peptides_batch(allf)
+    assert len(out) == 4 * n_cycles
+    for idx in (5, 4 * n_cycles - 2):
+        rows, fits, keep, key = O.find_peptides(allf[idx], n_threads=16)
+        _same_table(out[idx], rows, fits, keep, key)
+    for f in range(6):                                      # channel 0, the frames of the tracking golden
+        assert np.array_equal(np.array(list(out[f].keys()), dtype=np.int32).reshape(-1, 2), ref_hw[f])
+    # registration of channel 0
+    imgs = [fl.Image(image=fr) for fr in frames0]
+    for im, table in zip(imgs, out[:n_cycles]):
+        im._append_spots(table, spots_append=False)
+    ex = fl.SequenceExperiment(peptide_frames=imgs, alignment_frames=imgs)
+    offsets = [(float(a), float(b)) for a, b in ex.offsets_from_frames(upsample_factor=20)]
+    assert offsets[:6] == [(float(a), float(b)) for a, b in ref_offsets]
+    for k in range(1, 5):
+        assert offsets[k] == (float(gold["out_cycle512_%d_uf20" % k][0]), float(gold["out_cycle512_%d_uf20" % k][1]))
+    for f in (6, 7):
+        exp = O.phase_correlate(frames0[f - 1], frames0[f], 20)
+        assert offsets[f] == (exp[0], exp[1])
+    # tracking: the whole stack against the oracle tracker, its six-frame prefix against the reference's traces
+    frame_hw = [np.array([(s.h, s.w) for s in im.spots], dtype=np.int32).reshape(-1, 2) for im in imgs]
+    tr = ex.trace_existing_spots()
+    flat = [s for im in imgs for s in im.spots]
+    index = {id(s): i for i, s in enumerate(flat)}
+    got = np.array([[(-1 if s is None else index[id(s)]) for s in row] for row in tr], dtype=np.int64).reshape(-1, n_cycles)
+    o_tr, o_nd, _, _, _ = O.greedy_tracking(frame_hw, offsets, shape, radius, spot_radius)
+    assert ex.num_discarded_spots == o_nd and np.array_equal(got, o_tr)
+    ex6 = fl.SequenceExperiment(peptide_frames=imgs[:6], alignment_frames=imgs[:6], offsets=offsets[:6])
+    tr6 = ex6.trace_existing_spots()
+    got6 = [[(-1 if s is None else index[id(s)]) for s in row] for row in tr6]
+    assert ex6.num_discarded_spots == ref_discarded and got6 == ref_traces.tolist()
 
 
 def test_config5_large_dense_field(env):
