@@ -86,6 +86,7 @@ _SIGS = {
     "fsq_selftest_square": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64),
                                            ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p]),
     "fsq_fit_last_slow_count": (ctypes.c_int64, []),
+    "fsq_has_ab_engines": (ctypes.c_int, []),
 }
 EXPORTED = tuple(_SIGS)
 
@@ -103,7 +104,7 @@ def lib():
             try:
                 f = getattr(L, name)      # AttributeError if the library lacks a declared symbol
             except AttributeError:
-                if os.environ.get("FSQ_HIP_LIB") and name.startswith("fsq_selftest"):
+                if os.environ.get("FSQ_HIP_LIB") and (name.startswith("fsq_selftest") or name == "fsq_has_ab_engines"):
                     continue              # (an older A/B build without a newer self-test hook)
                 raise
             f.restype = res

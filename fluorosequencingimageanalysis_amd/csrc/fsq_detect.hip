@@ -127,6 +127,10 @@ __global__ void __launch_bounds__(256) k1_response(const uint16_t* __restrict__ 
         int v = 0;
         if (gh >= 0 && gh < H && gw >= 0 && gw < W) {
             int m;
+#ifdef FSQ_EXPERIMENT_NO_MEDIAN      // cost split of k1: the exact 25-sample median replaced by the centre's left neighbour (wrong results)
+            if (FAST5) m = raw[(rr + mo) * RW + cc + mo - 1];
+            else
+#endif
             if (FAST5) {
                 int s[25];
 #pragma unroll

@@ -5,6 +5,7 @@
 #include "fsq_common.h"
 #include "fsq_lm_core.h"
 
+#ifdef FSQ_BUILD_AB      // the one-lane-per-fit persistent engine: an A/B build only (make AB=1), not in the shipped library
 // pflib.illumina_s_n (pflib.py:261-281) on a 5x5 ROI held as doubles
 FSQ_DEV double fsq_illumina_s_n(const double* s, double vmax)
 {
@@ -111,6 +112,8 @@ __global__ void __launch_bounds__(64) fsq_fit_persistent(const uint16_t* __restr
     }
 }
 
+#endif  // FSQ_BUILD_AB
+
 __global__ void fsq_fit_images_kernel(const FsqRow* __restrict__ rows, const int32_t* __restrict__ idx, int64_t n,
                                       double* __restrict__ out)
 {
@@ -123,6 +126,7 @@ __global__ void fsq_fit_images_kernel(const FsqRow* __restrict__ rows, const int
     for (int k = 0; k < FSQ_NPIX; k++) out[i * FSQ_NPIX + k] = g[k];
 }
 
+#ifdef FSQ_BUILD_AB
 static int fsq_launch_fit(const uint16_t* d_src, int H, int W, const int32_t* d_cand, int64_t n, int mode, bool from_image,
                           FsqRow* d_rows, hipStream_t s)
 {
@@ -151,6 +155,7 @@ static int fsq_launch_fit(const uint16_t* d_src, int H, int W, const int32_t* d_
 
 int fsq_launch_fit_quad(const uint16_t* d_src, int H, int W, const int32_t* d_cand, int64_t n, int mode, bool from_image,
                         FsqRow* d_rows, void* d_ws, int64_t ws_bytes, hipStream_t s);
+#endif
 int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_cand, int64_t n, int mode, bool from_image,
                           FsqRow* d_rows, void* d_ws, int64_t ws_bytes, hipStream_t s);
 
@@ -161,11 +166,17 @@ extern "C" int fsq_fit_candidates(const uint16_t* d_img, int n_fields, int H, in
     if (n < 0 || H < 5 || W < 5 || n_fields < 1 || (m != FSQ_MODE_REF && m != FSQ_MODE_TEXTBOOK)) return FSQ_EINVAL;
     if (n == 0) return FSQ_OK;
     if (!d_img || !d_cand || !d_rows) return FSQ_EINVAL;
+#ifndef FSQ_BUILD_AB
+    if (mode & (FSQ_ENGINE_LANE | FSQ_ENGINE_QUAD)) return FSQ_ENOTIMPL;          // the A/B engines are not in this build
+#else
     if ((mode & FSQ_PIXELS_F16_FLAG) && (mode & (FSQ_ENGINE_LANE | FSQ_ENGINE_QUAD))) return FSQ_ENOTIMPL;   // A/B engines: uint16 only
+#endif
     if (mode & FSQ_PIXELS_F16_FLAG)
         return fsq_launch_fit_rounds(d_img, H, W, d_cand, n, m | FSQ_PIXELS_F16_FLAG, true, d_rows, d_workspace, workspace_bytes, (hipStream_t)stream);
+#ifdef FSQ_BUILD_AB
     if (mode & FSQ_ENGINE_LANE) return fsq_launch_fit(d_img, H, W, d_cand, n, m, true, d_rows, (hipStream_t)stream);
     if (mode & FSQ_ENGINE_QUAD) return fsq_launch_fit_quad(d_img, H, W, d_cand, n, m, true, d_rows, d_workspace, workspace_bytes, (hipStream_t)stream);
+#endif
     return fsq_launch_fit_rounds(d_img, H, W, d_cand, n, m, true, d_rows, d_workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -176,8 +187,12 @@ extern "C" int fsq_fit_rois(const uint16_t* d_rois, int64_t n, int mode, FsqRow*
     if (n < 0 || (m != FSQ_MODE_REF && m != FSQ_MODE_TEXTBOOK)) return FSQ_EINVAL;
     if (n == 0) return FSQ_OK;
     if (!d_rois || !d_rows) return FSQ_EINVAL;
+#ifdef FSQ_BUILD_AB
     if (mode & FSQ_ENGINE_LANE) return fsq_launch_fit(d_rois, 5, 5, nullptr, n, m, false, d_rows, (hipStream_t)stream);
     if (mode & FSQ_ENGINE_QUAD) return fsq_launch_fit_quad(d_rois, 5, 5, nullptr, n, m, false, d_rows, d_workspace, workspace_bytes, (hipStream_t)stream);
+#else
+    if (mode & (FSQ_ENGINE_LANE | FSQ_ENGINE_QUAD)) return FSQ_ENOTIMPL;
+#endif
     return fsq_launch_fit_rounds(d_rois, 5, 5, nullptr, n, m, false, d_rows, d_workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -189,4 +204,13 @@ extern "C" int fsq_fit_images(const FsqRow* d_rows, const int32_t* d_idx, int64_
     hipLaunchKernelGGL(fsq_fit_images_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, d_rows, d_idx, n, d_fit_img);
     FSQ_HIP_CHECK(hipGetLastError());
     return FSQ_OK;
+}
+
+extern "C" int fsq_has_ab_engines(void)
+{
+#ifdef FSQ_BUILD_AB
+    return 1;
+#else
+    return 0;
+#endif
 }

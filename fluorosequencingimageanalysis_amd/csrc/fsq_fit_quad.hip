@@ -2,6 +2,8 @@
 //   k3_prep    per candidate: median / max / mean of the 5x5 ROI (start values of pflib.py:199-213)
 //   k3_quad    persistent, 4 lanes per fit, work queue with refill: the LM solve (mpfit.py:600-1388)
 //   k3_finish  per candidate: fit image, r_2, rmse, illumina_s_n, image coordinates (pflib.py:461-475)
+// A/B build only (make AB=1): the shipped library carries the rounds engine (fsq_fit_rounds.hip) alone.
+#ifdef FSQ_BUILD_AB
 #include <atomic>
 
 #include "fsq_common.h"
@@ -591,3 +593,5 @@ int fsq_launch_fit_quad(const uint16_t* d_src, int H, int W, const int32_t* d_ca
     FSQ_HIP_CHECK(hipGetLastError());
     return FSQ_OK;
 }
+
+#endif  // FSQ_BUILD_AB

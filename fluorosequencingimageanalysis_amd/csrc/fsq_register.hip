@@ -109,39 +109,47 @@ __global__ void k6_cross_power2(const cplx* __restrict__ F, const cplx* __restri
 __device__ __forceinline__ double fftfreq_idx(int i, int n) { return (double)((i + n / 2) % n) - floor(n / 2.0); }  // ifftshift(arange(n)) - floor(n/2)
 
 // _dftups (phase_correlate.py:137-196): out[u][v] = sum_r sum_c rk[u][r] * data[r][c] * ck[c][v].
-// grid = (up, pairs); block = 256; dynamic LDS = (rows + cols) complex.
-//   stage 1: the row kernel rk[u][.] of this block's u is evaluated ONCE into LDS (rows sincos instead of rows x cols),
-//            then T[c] = sum_r rk[u][r] * data[r][c], thread per column, r in order (coalesced reads of data);
+// grid = (up, pairs); block = 256; dynamic LDS = (DFT_RC + DFT_TC) complex - ANY rows x cols.
+//   stage 1: the row kernel rk[u][.] of this block's u is evaluated once (rows sincos instead of rows x cols), DFT_RC rows
+//            at a time into LDS; T[c] = sum_r rk[u][r] * data[r][c], thread per column, r in order over all row chunks
+//            (coalesced reads of data).  T lives in LDS when cols <= DFT_TC, else in the caller's scratch Tg - every
+//            thread only ever touches its own columns, so the partial sums carry over between chunks without hazards;
 //   stage 2: out[u][v] = sum_c T[c] * ck[c][v]: every thread takes the columns c = tid, tid + 256, ..., the partial sums
 //            are combined by a fixed-shape tree (wave shuffles, then the 4 waves in order) - deterministic.
+constexpr int DFT_RC = 1536, DFT_TC = 1536;
 __global__ void __launch_bounds__(256) k6_dftups(const cplx* __restrict__ data, int rows, int cols, int up, int uf,
                                                  const double* __restrict__ offs /*[pairs][2] row_off, col_off*/,
-                                                 cplx* __restrict__ out /*[pairs][up][up]*/)
+                                                 cplx* __restrict__ out /*[pairs][up][up]*/, cplx* __restrict__ Tg /*[pairs][up][cols] or null*/)
 {
     extern __shared__ cplx lds_c[];
-    cplx* Wr = lds_c;                                 // [rows]
-    cplx* T = lds_c + rows;                           // [cols]
+    cplx* Wr = lds_c;                                 // [min(rows, DFT_RC)]
     __shared__ cplx wsum[4];
     const int u = blockIdx.x, pair = blockIdx.y, tid = threadIdx.x;
+    cplx* T = (cols <= DFT_TC) ? lds_c + DFT_RC : Tg + ((size_t)pair * up + u) * cols;
     const cplx* d = data + (size_t)pair * rows * cols;
     const double roff = offs[2 * pair], coff = offs[2 * pair + 1];
     const double cr = -2.0 * 3.141592653589793 / ((double)rows * uf), cc = -2.0 * 3.141592653589793 / ((double)cols * uf);
-    for (int r = tid; r < rows; r += blockDim.x) {
-        double ph = cr * (((double)u - roff) * fftfreq_idx(r, rows));
-        double s, co;
-        sincos(ph, &s, &co);
-        Wr[r] = make_double2(co, s);
-    }
-    __syncthreads();
-    for (int c = tid; c < cols; c += blockDim.x) {
-        cplx acc = make_double2(0., 0.);
-        for (int r = 0; r < rows; r++) {
-            const cplx w = Wr[r];
-            const cplx v = d[(size_t)r * cols + c];
-            acc.x += w.x * v.x - w.y * v.y;
-            acc.y += w.x * v.y + w.y * v.x;
+    for (int c = tid; c < cols; c += blockDim.x) T[c] = make_double2(0., 0.);
+    for (int r0 = 0; r0 < rows; r0 += DFT_RC) {
+        const int nr = min(DFT_RC, rows - r0);
+        __syncthreads();
+        for (int r = tid; r < nr; r += blockDim.x) {
+            double ph = cr * (((double)u - roff) * fftfreq_idx(r0 + r, rows));
+            double s, co;
+            sincos(ph, &s, &co);
+            Wr[r] = make_double2(co, s);
         }
-        T[c] = acc;
+        __syncthreads();
+        for (int c = tid; c < cols; c += blockDim.x) {
+            cplx acc = T[c];
+            for (int r = 0; r < nr; r++) {
+                const cplx w = Wr[r];
+                const cplx v = d[(size_t)(r0 + r) * cols + c];
+                acc.x += w.x * v.x - w.y * v.y;
+                acc.y += w.x * v.y + w.y * v.x;
+            }
+            T[c] = acc;
+        }
     }
     __syncthreads();
     for (int v = 0; v < up; v++) {
@@ -475,7 +483,7 @@ int get_plan(int H, int W, int batch, int kind, hipStream_t s, PlanEntry* out)
 }
 
 struct RegLayout {
-    size_t A, B, Fh, Gh, Ph, cc, T, rkT, U, psums, sums, shifts, offs, part, peaks, fftwork, total;
+    size_t A, B, Fh, Gh, Ph, cc, T, rkT, Tg, U, psums, sums, shifts, offs, part, peaks, fftwork, total;
     int parts, Wh, up, Mp; bool real_path, mfma;
 };
 
@@ -507,6 +515,7 @@ RegLayout reg_layout(int n_pairs, int H, int W, int uf, int dtype, bool real_pat
         L.Fh = take(n_pairs * npix * 16); L.Gh = take(n_pairs * npix * 16); L.Ph = take(n_pairs * npix * 16);
         L.cc = L.T = L.rkT = 0;             // (the full-spectrum path re-uses F and G for rkT and T)
     }
+    L.Tg = take(uf > 1 && !L.mfma && W > DFT_TC ? (size_t)n_pairs * L.up * W * 16 : 0);     // vector-ALU DFT: T rows too long for LDS
     L.U = take(uf > 1 ? (size_t)n_pairs * L.up * L.up * 16 : 0);
     L.psums = take((size_t)n_pairs * 1024 * 16);
     L.sums = take((size_t)n_pairs * 16); L.shifts = take((size_t)n_pairs * 16); L.offs = take((size_t)n_pairs * 16);
@@ -601,9 +610,9 @@ extern "C" int fsq_phase_correlate(const void* d_ref, const void* d_reg, int dty
                 hipLaunchKernelGGL(k6_dft_mfma_half, dim3(W / 16, (Mp + 31) / 32, n_pairs), dim3(64), 0, s, Fh, Gh, rkT, H, W, Wh, Mp, T);
                 hipLaunchKernelGGL(k6_dft_cols, dim3(up, n_pairs), dim3(256), 0, s, T, W, Mp, up, uf, offs, U);
             } else {
-                if ((size_t)(H + W) * sizeof(cplx) > 60000) return FSQ_ENOTIMPL;        // the twiddle vectors live in LDS
                 hipLaunchKernelGGL(k6_expand_gf, dim3((unsigned)((npix + 255) / 256), n_pairs), dim3(256), 0, s, Fh, Gh, H, W, Wh, T);
-                hipLaunchKernelGGL(k6_dftups, dim3(up, n_pairs), dim3(256), (size_t)(H + W) * sizeof(cplx), s, T, H, W, up, uf, offs, U);
+                hipLaunchKernelGGL(k6_dftups, dim3(up, n_pairs), dim3(256), (size_t)(DFT_RC + DFT_TC) * sizeof(cplx), s, T, H, W, up, uf, offs, U,
+                                   (cplx*)(ws + L.Tg));
             }
         }
     } else {
@@ -633,8 +642,8 @@ extern "C" int fsq_phase_correlate(const void* d_ref, const void* d_reg, int dty
                 hipLaunchKernelGGL(k6_dft_mfma, dim3(W / 16, (Mp + 31) / 32, n_pairs), dim3(64), 0, s, P, rkT, H, W, Mp, Tm);
                 hipLaunchKernelGGL(k6_dft_cols, dim3(up, n_pairs), dim3(256), 0, s, Tm, W, Mp, up, uf, offs, U);
             } else {
-                if ((size_t)(H + W) * sizeof(cplx) > 60000) return FSQ_ENOTIMPL;
-                hipLaunchKernelGGL(k6_dftups, dim3(up, n_pairs), dim3(256), (size_t)(H + W) * sizeof(cplx), s, P, H, W, up, uf, offs, U);
+                hipLaunchKernelGGL(k6_dftups, dim3(up, n_pairs), dim3(256), (size_t)(DFT_RC + DFT_TC) * sizeof(cplx), s, P, H, W, up, uf, offs, U,
+                                   (cplx*)(ws + L.Tg));
             }
         }
     }

@@ -50,9 +50,39 @@ def track_fields(fields, offsets, frame_shape, candidate_radius=2, spot_radius=0
     hw = np.ascontiguousarray(np.concatenate(parts) if parts else np.zeros((0, 2), np.int32))
     start = np.concatenate([[0], np.cumsum(counts.sum(axis=1))]).astype(np.int32)
     total = int(start[-1])
+    # the kernel's limits (csrc/fsq_track.hip: one block walks a field with its spot flags in LDS); the reference has none
+    if F > TRACK_MAX_FRAMES:
+        raise NotImplementedError("greedy tracking on the GPU handles at most %d frames per field (got %d)" % (TRACK_MAX_FRAMES, F))
+    if counts.size and int(counts.sum(axis=1).max()) > TRACK_MAX_SPOTS:
+        raise NotImplementedError("greedy tracking on the GPU handles at most %d spots per field, all frames together (got %d)"
+                                  % (TRACK_MAX_SPOTS, int(counts.sum(axis=1).max())))
     off = np.ascontiguousarray(np.array([[(float(o[0]), float(o[1])) for o in offs] for offs in offsets], dtype=np.float64))
-    pair_cap = max(4096, 8 * int(counts.max()) if counts.size else 4096)
+    for k in range(n_fields):
+        if off[k, 0, 0] != 0 or off[k, 0, 1] != 0:
+            raise ValueError("The first image's offset must be (0, 0) by definiton.")           # flexlibrary.py:581-583
     L = N.lib()
+    pair_cap = max(4096, 8 * int(counts.max()) if counts.size else 4096)
+    while True:         # candidate pairs per frame are bounded only by the data: on overflow the list is doubled and the call repeated
+        res = _track_launch(torch, dev, L, hw, start, counts, off, n_fields, F, H, W, candidate_radius, spot_radius, pair_cap, total)
+        if not (res[0] == N.FSQ_ERANGE).any() or pair_cap >= (1 << 28):
+            break
+        pair_cap *= 4
+    st, nt, nd, prev, nxt, kept, traces = res
+    out = []
+    for k in range(n_fields):
+        if st[k] == N.FSQ_EASSERT:
+            raise AssertionError("field %d: two spots of one frame round to the same bin of frame_bins "
+                                 "(flexlibrary.py:851)" % k)
+        N.check(int(st[k]), "fsq_greedy_tracking (field %d)" % k)
+        a, b = int(start[k]), int(start[k + 1])
+        out.append((traces[a:a + int(nt[k])].copy(), int(nd[k]), prev[a:b].copy(), nxt[a:b].copy(), kept[a:b].copy()))
+    return out
+
+
+TRACK_MAX_FRAMES, TRACK_MAX_SPOTS = 64, 32768
+
+
+def _track_launch(torch, dev, L, hw, start, counts, off, n_fields, F, H, W, candidate_radius, spot_radius, pair_cap, total):
     ws_bytes = L.fsq_track_workspace_bytes(n_fields, H, W, pair_cap)
     if ws_bytes < 0:
         raise ValueError("invalid tracking shape")
@@ -71,20 +101,8 @@ def track_fields(fields, offsets, frame_shape, candidate_radius=2, spot_radius=0
                                d_kept.data_ptr(), d_traces.data_ptr(), d_nt.data_ptr(), d_nd.data_ptr(), d_st.data_ptr(),
                                pair_cap, ws.data_ptr(), ws_bytes, torch.cuda.current_stream(dev).cuda_stream)
     N.check(rc, "fsq_greedy_tracking")
-    st, nt, nd = d_st.cpu().numpy(), d_nt.cpu().numpy(), d_nd.cpu().numpy()
-    prev, nxt, kept = d_prev.cpu().numpy(), d_next.cpu().numpy(), d_kept.cpu().numpy().astype(bool)
-    traces = d_traces.cpu().numpy().reshape(-1, F)
-    out = []
-    for k in range(n_fields):
-        if st[k] == N.FSQ_EINVAL:
-            raise ValueError("The first image's offset must be (0, 0) by definiton.")           # flexlibrary.py:581-583
-        if st[k] == N.FSQ_EASSERT:
-            raise AssertionError("field %d: two spots of one frame round to the same bin of frame_bins "
-                                 "(flexlibrary.py:851)" % k)
-        N.check(int(st[k]), "fsq_greedy_tracking (field %d)" % k)
-        a, b = int(start[k]), int(start[k + 1])
-        out.append((traces[a:a + int(nt[k])].copy(), int(nd[k]), prev[a:b].copy(), nxt[a:b].copy(), kept[a:b].copy()))
-    return out
+    return (d_st.cpu().numpy(), d_nt.cpu().numpy(), d_nd.cpu().numpy(), d_prev.cpu().numpy(), d_next.cpu().numpy(),
+            d_kept.cpu().numpy().astype(bool), d_traces.cpu().numpy().reshape(-1, F))
 
 
 def centroid_track_fields(frames, init_hw, spot_field=None, search_radius=3, s_n_cutoff=3.0, offsets=None, device=None):

@@ -278,6 +278,9 @@ int fsq_selftest_exp(const double* d_x, int64_t n, int64_t* mismatches, void* st
  * (must be 0), and those for which it does not hold (*undecided; about 3 % of random arguments). */
 int fsq_selftest_square(const double* d_t, int64_t n, int64_t* mismatches, int64_t* undecided, void* stream);
 int64_t fsq_fit_last_slow_count(void);
+/* 1 when the library was built with the two single-launch A/B engines (make AB target, -DFSQ_BUILD_AB): only then do
+ * FSQ_ENGINE_LANE / FSQ_ENGINE_QUAD select them; the shipped library returns FSQ_ENOTIMPL for those flags. */
+int fsq_has_ab_engines(void);
 
 #ifdef __cplusplus
 }

@@ -137,7 +137,7 @@ int fsq_o_greedy_tracking(int n_frames, const int32_t* counts, const int32_t* hw
                         }
                     }
             }
-        qsort(pairs, np, sizeof(Pair), pair_cmp);                         /* (keys are unique: a total order) */
+        if (np > 1) qsort(pairs, np, sizeof(Pair), pair_cmp);             /* (keys are unique: a total order) */
         for (size_t k = 0; k < np; k++) {
             const Pair* p = &pairs[k];
             if (cache[p->a_cell] == -1) continue;                         /* ancestor has been paired */

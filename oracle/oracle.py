@@ -44,7 +44,9 @@ def lib(libm=False):
     name = "libfsq_oracle_libm.so" if libm else "libfsq_oracle.so"
     if name not in _libs:
         path = os.path.join(HERE, name)
-        if not os.path.exists(path):
+        if os.environ.get("FSQ_ORACLE_LIB") and not libm:      # (tests/test_sanitizers.py: an ASan / UBSan build of the same sources)
+            path = os.environ["FSQ_ORACLE_LIB"]
+        elif not os.path.exists(path):
             build()
         L = ctypes.CDLL(path)
         L.fsq_o_illumina_s_n.restype = ctypes.c_double

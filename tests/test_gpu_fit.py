@@ -1,10 +1,12 @@
 """GPU parity tests (-m gpu): the HIP LM kernel, called through the C ABI (include/fsq.h), against the
 oracle on the same ROIs.  Integer/IEEE path: the bar is BIT equality of every fitted parameter, the
 exit status, iteration and evaluation counts, and the fit-quality metrics."""
+import os
+
 import numpy as np
 import pytest
 
-from _util import DEGEN_NAMES, FIELD_NAMES, TEXTBOOK_NAMES, bits_equal, load_field, rois_of
+from _util import DEGEN_NAMES, FIELD_NAMES, ROOT, TEXTBOOK_NAMES, bits_equal, load_field, rois_of
 
 pytestmark = pytest.mark.gpu
 
@@ -57,16 +59,39 @@ def test_fit_rois_bit_exact_vs_oracle_and_golden(env, name):
             assert bits_equal(got[k][i], exp[k][i]).all(), (k, i)
 
 
-@pytest.mark.parametrize("name", ["f3_hard_256", "f1_cfg2_512_500"])
-def test_lane_engine_equals_quad_engine(env, name):
-    """the one-lane-per-fit engine (FSQ_ENGINE_LANE) and the quad engine give identical rows"""
+def test_ab_engines_equal_production_engine(env):
+    """The two single-launch persistent engines (FSQ_ENGINE_LANE: one lane per fit, FSQ_ENGINE_QUAD: a quad of lanes per fit)
+    live in the A/B build of the library only (csrc/ab/libfsq_hip_ab.so, `make ab`); the shipped library refuses the flags.
+    A child interpreter loads the A/B build and compares all three engines on two golden fields, bit for bit."""
+    import subprocess
+    import sys
     torch, N, O = env
+    g, img = load_field("f3_hard_256")
+    rois = rois_of(img, g["candidates"])[:64]
+    assert N.lib().fsq_has_ab_engines() == 0
+    with pytest.raises(NotImplementedError):
+        gpu_fit_rois(torch, N, rois, mode=0 | N.ENGINE_LANE)
+    ab = os.path.join(ROOT, "fluorosequencingimageanalysis_amd", "csrc", "ab", "libfsq_hip_ab.so")
+    assert os.path.exists(ab), "build it with `make -C fluorosequencingimageanalysis_amd/csrc ab` (__graft_entry__.build() does)"
+    code = """
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+from fluorosequencingimageanalysis_amd import _native as N
+from _util import load_field, rois_of
+from test_gpu_fit import gpu_fit_rois
+assert N.lib().fsq_has_ab_engines() == 1
+for name in ("f3_hard_256", "f1_cfg2_512_500"):
     g, img = load_field(name)
     rois = rois_of(img, g["candidates"])
     a = gpu_fit_rois(torch, N, rois, mode=0)
     b = gpu_fit_rois(torch, N, rois, mode=0 | N.ENGINE_LANE)
     c = gpu_fit_rois(torch, N, rois, mode=0 | N.ENGINE_QUAD)
-    assert a.tobytes() == b.tobytes() == c.tobytes()
+    assert a.tobytes() == b.tobytes() == c.tobytes(), name
+print("engines agree")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, FSQ_HIP_LIB=ab), timeout=600)
+    assert p.returncode == 0 and "engines agree" in p.stdout, (p.stdout + p.stderr)[-2000:]
 
 
 def _rows_equal_golden(got, g):

@@ -102,14 +102,37 @@ def test_two_threads_on_their_own_streams(pc):
     assert np.array_equal(res[0], ref) and np.array_equal(res[1], ref)
 
 
-def test_unsupported_shape_fails_loudly(pc):
-    """A shape whose upsampled DFT fits neither the MFMA tiles nor the LDS twiddle vectors is refused
-    (NotImplementedError), not answered with garbage; many distinct batch sizes do not pile up plans."""
+def _shifted(rng, H, W, dh, dw):
+    """Smooth random content and a copy circularly shifted by (dh, dw) pixels (a Fourier-domain shift: any real dh, dw)."""
+    base = rng.normal(0, 1, (H, W))
+    F = np.fft.fft2(base)
+    F *= np.exp(-0.5 * ((np.fft.fftfreq(H)[:, None] * 40) ** 2 + (np.fft.fftfreq(W)[None, :] * 40) ** 2))      # low-pass
+    ref = np.fft.ifft2(F).real
+    ramp = np.exp(-2j * np.pi * (np.fft.fftfreq(H)[:, None] * dh + np.fft.fftfreq(W)[None, :] * dw))
+    return ref, np.fft.ifft2(F * ramp).real
+
+
+def test_any_shape_registers(pc):
+    """phase_correlate.py:137-196 works for any H x W: shapes that fit neither the MFMA tiles (cols % 16, rows % 4) nor the
+    LDS of the vector-ALU DFT in one piece (2 048 x 2 050: its twiddle vectors and partial sums are tiled), prime x prime
+    (Bluestein FFT lengths): the recovered shift equals the one put in on the 1 / upsample_factor grid; a small prime shape
+    equals the oracle; many distinct batch sizes do not pile up plans."""
+    import oracle as O
+    rng = np.random.default_rng(5)
+    for (H, W), (dh, dw) in (((2048, 2050), (7.0, -11.0)), ((2048, 2050), (-3.35, 0.65)), ((1031, 1033), (12.4, -7.7)),
+                             ((3001, 40), (-1.25, 2.0))):
+        ref, reg = _shifted(rng, H, W, dh, dw)
+        r = pc.phase_correlate(ref, reg, upsample_factor=20)
+        assert abs(float(r[0]) + dh) < 1e-9 and abs(float(r[1]) + dw) < 1e-9, ((H, W), (dh, dw), r)
+        assert float(r[2]) < 1e-3
     a = np.zeros((1, 2048, 2050), np.uint16)
     a[0, 100, 100] = 1000
-    with pytest.raises(NotImplementedError):
-        pc.phase_correlate_batch(a, a, 20)
+    assert pc.phase_correlate_batch(a, a, 20)[0][:2].tolist() == [0.0, 0.0]
     assert pc.phase_correlate_batch(a, a, 1)[0][:2].tolist() == [0.0, 0.0]
+    ref, reg = _shifted(rng, 61, 67, 2.3, -4.45)
+    r, e = pc.phase_correlate(ref, reg, upsample_factor=20), O.phase_correlate(ref, reg, 20)
+    # (error = sqrt(|1 - peak^2 / (amp amp)|) of an exact shift is the square root of rounding noise: compare its square)
+    assert float(r[0]) == e[0] and float(r[1]) == e[1] and abs(float(r[2]) ** 2 - e[2] ** 2) < 1e-12 and abs(float(r[3]) - e[3]) < 1e-9
     img = np.random.default_rng(0).integers(0, 4000, (40, 32, 48)).astype(np.uint16)
     for n in range(1, 40, 3):                           # 13 batch sizes x 2 plans: beyond the cache bound
         r = pc.phase_correlate_batch(img[:n], np.roll(img[:n], (2, -3), axis=(1, 2)), 1)

@@ -87,6 +87,24 @@ def test_tracking_errors(env):
         fl.Experiment.accumulate_offsets([(0, 1), (0, 0)])
     with pytest.raises(TypeError):
         fl.Experiment.greedy_particle_tracking([[]], (8, 8))
+    # the kernel's limits are named (the reference has none): 64 frames, 32 768 spots per field
+    with pytest.raises(NotImplementedError, match="64 frames"):
+        fl.track_fields([[np.zeros((0, 2), np.int32)] * 65], [[(0, 0)] * 65], (12, 12))
+    lattice = np.array([(h, w) for h in range(182) for w in range(182)], np.int32)          # 33 124 spots in one frame
+    with pytest.raises(NotImplementedError, match="32768 spots"):
+        fl.track_fields([[lattice]], [[(0, 0)]], (200, 200))
+
+
+def test_pair_list_grows_on_demand(env):
+    """A wide candidate radius on a dense lattice produces far more candidate pairs than the first guess of the pair list
+    (8 x the largest frame): the call is repeated with a longer list instead of failing, and equals the oracle."""
+    torch, N, fl, O = env
+    base = np.array([(h, w) for h in range(4, 60, 2) for w in range(4, 60, 2)], np.int32)   # 784 spots, 2 px apart
+    frames = [base, base + np.array([0, 1], np.int32), base]
+    offsets = [(0, 0), (0, 0), (0, 0)]
+    got, nd, prev, nxt, kept = fl.track_fields([frames], [offsets], (64, 64), candidate_radius=7)[0]
+    o_tr, o_nd, o_prev, o_next, o_kept = O.greedy_tracking(frames, offsets, (64, 64), 7, 0)
+    assert nd == o_nd and np.array_equal(got, o_tr) and np.array_equal(prev, o_prev) and np.array_equal(nxt, o_next)
 
 
 def test_x87_dnrm2_restatement(env):
