@@ -44,15 +44,6 @@ def make_fields(seeds, shape, n_spots):
     return out
 
 
-def library_sha16(path):
-    import hashlib
-    h = hashlib.sha256()
-    with open(path, "rb") as f:
-        for blk in iter(lambda: f.read(1 << 20), b""):
-            h.update(blk)
-    return h.hexdigest()[:16]
-
-
 def cpu_baseline(imgs, cand, counts, offsets, n_threads):
     """The oracle (C restatement of the reference) on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -141,18 +132,18 @@ def main():
         # region; lanes: the time at least one lane's fit launch was running)
         achieved = total * a.steps * FLOP_PER_FIT / (busy_ms * 1e-3) / 1e12
         # PMC-derived figures (HBM bytes, issue fractions) cannot be collected inside this run (rocprofv3 --pmc serialises the
-        # kernels): they come from profiles/fit_counters_latest.json, which records the library build it was taken on, and are
-        # only reported when that is the library loaded now - otherwise null with stale = true.
+        # kernels): they come from profiles/fit_counters_latest.json, which records the hash of the kernel sources it was taken on, and are
+        # only reported when the sources are still those - otherwise null with stale = true.
         prof, from_profile = {}, {"stale": True}
         ppath = os.path.join(ROOT, "profiles", "fit_counters_latest.json")
-        lib_sha = library_sha16(N.LIB_PATH)
+        lib_sha = N.source_sha16()
         if os.path.exists(ppath):
             prof = json.load(open(ppath))
-            if prof.get("library_sha16") == lib_sha:
+            if prof.get("source_sha16") == lib_sha:
                 from_profile = dict(prof, stale=False, note="not measured in this run: separate rocprofv3 --pmc passes of the same library "
-                                                            "on %s fields per step (tools/collect_profiles_r03.sh)" % prof.get("fields_per_step"))
+                                                            "on %s fields per step (tools/collect_profiles.sh)" % prof.get("fields_per_step"))
             else:
-                from_profile = {"stale": True, "library_sha16_of_profile": prof.get("library_sha16"), "library_sha16_loaded": lib_sha}
+                from_profile = {"stale": True, "source_sha16_of_profile": prof.get("source_sha16"), "source_sha16_now": lib_sha}
                 prof = {}
         traffic = prof.get("fit_kernel_hbm_bytes_per_1024_field_step")
         if traffic is not None:

@@ -113,6 +113,21 @@ def lib():
     return _lib
 
 
+def source_sha16():
+    """Hash of the library's sources (csrc/*.hip, csrc/*.h, include/fsq.h): what profiles/fit_counters_latest.json records so
+    that counters taken on one version of the kernels are not reported for another (bench.py)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(HERE, "csrc", "*.hip")) + glob.glob(os.path.join(HERE, "csrc", "*.h")))
+    files.append(os.path.join(os.path.dirname(HERE), "include", "fsq.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def check(rc, what):
     if rc == FSQ_OK:
         return

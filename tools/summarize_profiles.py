@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""Condense the rocprofv3 output of tools/collect_profiles_r02.sh into gpurun_out/<round>/summary.{md,json} and
-fit_counters.json (what bench.py reads from profiles/fit_counters_latest.json)."""
+"""Condense the rocprofv3 output of tools/collect_profiles.sh into gpurun_out/<tag>/summary.{md,json} and fit_counters.json
+(what bench.py reads from profiles/fit_counters_latest.json; it carries the hash of the kernel sources the counters were taken on)."""
 import collections
 import csv
 import glob
 import json
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 base = "gpurun_out/%s" % R
 CLOCK_GHZ, N_SIMD = 2.4, 1024
 out = {"round": R}
@@ -83,7 +83,11 @@ md += ["## SQ counters of the fit kernels (256-field run, %s steps)" % steps_pmc
 names = sorted(set(acc["kA_jacobian"]) | set(acc["kB_step"]))
 for c in names:
     md.append("| %s | %.4g | %.4g |" % (c, acc["kA_jacobian"].get(c, 0), acc["kB_step"].get(c, 0)))
-fc = {"source": "profiles/%s_summary.json (rocprofv3 --pmc, tools/collect_profiles_r02.sh)" % R}
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fluorosequencingimageanalysis_amd import _native as _N  # noqa: E402
+fc = {"source": "profiles/%s_summary.json (rocprofv3 --pmc, tools/collect_profiles.sh)" % R, "source_sha16": _N.source_sha16(),
+      "fields_per_step": 256}
 if "fit_kernel_hbm_bytes_per_1024_field_step" in out:
     fc["fit_kernel_hbm_bytes_per_1024_field_step"] = out["fit_kernel_hbm_bytes_per_1024_field_step"]
 va = sum(acc[k].get("SQ_ACTIVE_INST_VALU", 0) for k in ("kA_jacobian", "kB_step"))
