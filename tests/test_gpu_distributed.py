@@ -37,7 +37,16 @@ def _worker(rank, world, port, q, partition):
     from fluorosequencingimageanalysis_amd import distributed as D
     torch.cuda.set_device(0)
     D.init_from_env(backend="gloo")
-    out = D.find_peptides_sharded(_fields(), partition=partition, c_std=2)
+    if partition == "loader":                  # a per-rank loader: the rank only ever holds the fields it asks for
+        stack, asked = _fields(), set()
+
+        def loader(idx):
+            asked.update(idx)
+            return stack[list(idx)]
+        out = D.find_peptides_sharded(loader, n_fields=len(stack), partition="lpt", c_std=2)
+        assert 0 < len(asked) < len(stack), sorted(asked)      # its counting share + its LPT share, never the whole list
+    else:
+        out = D.find_peptides_sharded(_fields(), partition=partition, c_std=2)
     if rank == 0:
         q.put(out)
     else:
@@ -59,7 +68,7 @@ def _same_dicts(a, b):
                               np.array([float(vb[9]), float(vb[10]), float(vb[11])])).all()
 
 
-@pytest.mark.parametrize("partition", ["lpt", "round_robin"])
+@pytest.mark.parametrize("partition", ["lpt", "round_robin", "loader"])
 def test_sharded_equals_single_rank(partition):
     import torch
     assert torch.cuda.is_available(), "GPU tests need a GPU"
