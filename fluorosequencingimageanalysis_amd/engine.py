@@ -97,6 +97,18 @@ def detect_params(median_filter_size, correlation_matrix, c_std, pixel_format=N.
 PEAK_RECORD_BYTES = 128 + 200 + 50
 
 
+#: one peak record as a NumPy structure (unaligned: 378 bytes): the FsqRow fields + fit_img + the sub_img pixel words
+RECORD_DTYPE = np.dtype({"names": list(N.ROW_DTYPE.names) + ["fit", "sub"],
+                         "formats": [N.ROW_DTYPE.fields[k][0] for k in N.ROW_DTYPE.names] + [("<f8", (5, 5)), ("<u2", (5, 5))],
+                         "offsets": [N.ROW_DTYPE.fields[k][1] for k in N.ROW_DTYPE.names] + [128, 328],
+                         "itemsize": PEAK_RECORD_BYTES})
+
+
+def peak_record_view(rec):
+    """uint8[k, PEAK_RECORD_BYTES] (host, C-contiguous) -> RECORD_DTYPE[k] view of the same memory (no copy)."""
+    return np.ascontiguousarray(rec).reshape(-1, PEAK_RECORD_BYTES).view(RECORD_DTYPE).reshape(-1)
+
+
 def split_peak_records(rec, pixel_format=N.PIXELS_U16):
     """uint8[k, PEAK_RECORD_BYTES] (host) -> (rows FsqRow[k], fit_img float64[k, 5, 5], sub_img int64[k, 5, 5])."""
     rec = np.ascontiguousarray(rec).reshape(-1, PEAK_RECORD_BYTES)

@@ -131,28 +131,52 @@ def illumina_s_n(sub_img):
     return (np.amax(sub_img) - np.mean(edge)) / np.std(edge)
 
 
-def _records_to_dicts(rows, fit, sub, offs, failed=()):
-    """Peak records of a batch (engine.split_peak_records) -> one {(h, w): 12-tuple} per field, in the reference's
+#: _records_to_dicts converts about this many peaks per interpreter call (see there)
+DICT_SLICE_PEAKS = 2048
+
+
+def _records_to_dicts(rows, fit, sub, offs, failed=(), pixel_format=N.PIXELS_U16):
+    """Peak records of a batch -> one {(h, w): 12-tuple} per field, in the reference's
     dict order (pflib.py:396-407, 475, 514-519); fields listed in `failed` give an AssertionError instance instead.
     Built column-wise: the value types are the reference's (numpy.float64 scalars, a Python float for rmse, 5x5 arrays -
     views of the batch's sub_img / fit_img blocks), the tuples are zipped together and the dicts filled by the interpreter's
-    C loops; the cyclic garbage collector is held off meanwhile (millions of fresh containers, none of them cyclic)."""
+    C loops; the cyclic garbage collector is held off meanwhile (millions of fresh containers, none of them cyclic).
+    The table is worked off a few fields (DICT_SLICE_PEAKS peaks) at a time: every list() / zip() below is ONE call into the
+    interpreter's C code, during which no other thread can take the interpreter - and the thread that drives the GPU pipeline
+    needs it for a moment after each of its library calls.  With whole 60 000-peak chunks per call it waited milliseconds every
+    time and the GPU ran dry (the dict-building call measured 1 490 fields/s against 2 900 for the same call without dicts).
+    rows: FsqRow table with fit / sub as separate float64 / int64 [k, 5, 5] blocks (engine.split_peak_records), or - fit and
+    sub None - the records themselves (engine.peak_record_view): the 5x5 blocks are then copied out slice by slice too."""
     was_enabled = gc.isenabled()
     gc.disable()
     try:
-        cols = [list(np.ascontiguousarray(rows[k])) for k in ("h0", "w0", "H", "A", "sigma_h", "sigma_w", "theta")]
-        rmse = rows["rmse"].tolist()
-        r2 = list(np.ascontiguousarray(rows["r2"]))
-        s_n = list(np.ascontiguousarray(rows["s_n"]))
-        tuples = list(zip(*cols, list(sub), list(fit), rmse, r2, s_n))
-        keys = list(zip(rows["key_h"].tolist(), rows["key_w"].tolist()))
         offs = [int(x) for x in offs]
+        n_fields = len(offs) - 1
         out = []
-        for f in range(len(offs) - 1):
-            if f in failed:
-                out.append(AssertionError("field %d: re-keyed peak collides with an existing key (pflib.py:518)" % f))
+        f0 = 0
+        while f0 < n_fields:
+            f1 = f0 + 1
+            while f1 < n_fields and offs[f1 + 1] - offs[f0] <= DICT_SLICE_PEAKS:
+                f1 += 1
+            a, b = offs[f0], offs[f1]
+            part = rows[a:b]
+            cols = [list(np.ascontiguousarray(part[k])) for k in ("h0", "w0", "H", "A", "sigma_h", "sigma_w", "theta")]
+            rmse = part["rmse"].tolist()
+            r2 = list(np.ascontiguousarray(part["r2"]))
+            s_n = list(np.ascontiguousarray(part["s_n"]))
+            if fit is None:
+                fit_blk = np.ascontiguousarray(part["fit"])
+                sub_blk = _engine.pixel_values(np.ascontiguousarray(part["sub"]), pixel_format).reshape(-1, 5, 5)
             else:
-                out.append(dict(zip(keys[offs[f]:offs[f + 1]], tuples[offs[f]:offs[f + 1]])))
+                fit_blk, sub_blk = fit[a:b], sub[a:b]
+            tuples = list(zip(*cols, list(sub_blk), list(fit_blk), rmse, r2, s_n))
+            keys = list(zip(part["key_h"].tolist(), part["key_w"].tolist()))
+            for f in range(f0, f1):
+                if f in failed:
+                    out.append(AssertionError("field %d: re-keyed peak collides with an existing key (pflib.py:518)" % f))
+                else:
+                    out.append(dict(zip(keys[offs[f] - a:offs[f + 1] - a], tuples[offs[f] - a:offs[f + 1] - a])))
+            f0 = f1
         return out
     finally:
         if was_enabled:
@@ -190,6 +214,7 @@ class _BatchRunner:
         # chunk c is written again (chunk c + 4) only after the pipeline thread has recorded the upload event of chunk c
         self.pin = [torch.empty((self.per, H, W), dtype=torch.int16).pin_memory() for _ in range(4)]
         self.pin_ev = [None] * 4
+        self.rec_pin = None                     # pinned landing buffer of the peak records (dict-building calls)
         self.lock = threading.Lock()
 
     def close(self):
@@ -239,16 +264,20 @@ class _BatchRunner:
         def materialise(c, rec, offs, nk, ev):
             with torch.cuda.device(self.dev):
                 ev.synchronize()
-                rec_host = rec.cpu().numpy()
-                if not raw:
-                    rows, fit, sub = _engine.split_peak_records(rec_host, fmt)
-                nk = nk.cpu().numpy()
-                offs = offs.cpu().numpy()
+                if raw:
+                    rec_host = rec.cpu().numpy()
+                else:       # through a pinned buffer that is re-used (this thread works one chunk at a time): no fresh pages
+                    k = rec.shape[0]
+                    if self.rec_pin is None or self.rec_pin.shape[0] < k:
+                        self.rec_pin = torch.empty((k + k // 4 + 1024, _engine.PEAK_RECORD_BYTES), dtype=torch.uint8).pin_memory()
+                    self.rec_pin[:k].copy_(rec, non_blocking=True)
+                meta = torch.cat([nk.to(torch.int32), offs.to(torch.int32)]).cpu().numpy()    # (synchronises this thread's stream)
+                nk, offs = meta[:len(nk)], meta[len(nk):]
             if raw:
                 out[c] = (rec_host, np.where(nk < 0, nk, np.diff(offs)).astype(np.int32))
                 return
             failed = set(int(f) for f in np.nonzero(nk < 0)[0])
-            dicts = _records_to_dicts(rows, fit, sub, offs, failed)
+            dicts = _records_to_dicts(_engine.peak_record_view(self.rec_pin[:k].numpy()), None, None, offs, failed, fmt)
             out[c * per:(c + 1) * per] = dicts
             if on_chunk is not None:
                 on_chunk(c * per, dicts[:max(0, min(per, n - c * per))])
@@ -351,11 +380,10 @@ def find_peptides_records(images, median_filter_size=5, correlation_matrix=defau
 
 def records_to_dicts(records, counts, pixel_format=N.PIXELS_U16):
     """The inverse packaging of find_peptides_records: -> list of dicts (AssertionError instances for failed fields)."""
-    rows, fit, sub = _engine.split_peak_records(records, pixel_format)
     counts = np.asarray(counts).reshape(-1)
     failed = set(int(k) for k in np.nonzero(counts < 0)[0])
     offs = np.concatenate([[0], np.cumsum(np.maximum(counts, 0))])
-    return _records_to_dicts(rows, fit, sub, offs, failed)
+    return _records_to_dicts(_engine.peak_record_view(records), None, None, offs, failed, pixel_format)
 
 
 def count_candidates(images, median_filter_size=5, correlation_matrix=default_correlation_matrix, c_std=2, **unused):
