@@ -396,7 +396,8 @@ def run_lanes(a, torch, dist, D, E, N, d_img, prm, dev, rank, world):
 def extras(a, torch, E, N, pflib, imgs, d_img, prm, dev):
     """Side measurements SURVEY 8d lists next to the headline, taken in the same run: the stream pipeline with every step's
     images uploaded inside the timed region; the dict-materialising pflib surface; the command line end to end (TIFF -> pickle +
-    CSV); the registration step of configs[2]; the tracking and photometry kernels."""
+    CSV); the registration step of configs[2]; the tracking and photometry kernels; the opt-in single-precision
+    solver of configs[4] with its distance from the fp64 textbook solver (tools/bench_f32.py)."""
     import shutil
     import subprocess
     import tempfile
@@ -469,9 +470,9 @@ def extras(a, torch, E, N, pflib, imgs, d_img, prm, dev):
         r["pairs"], a.size, a.size, r["launch_ms"])
     # tracking and photometry kernels (their own processes: tools/bench_tracking.py, tools/bench_photometry.py)
     torch.cuda.empty_cache()
-    for script in ("bench_tracking.py", "bench_photometry.py"):
+    for script in ("bench_tracking.py", "bench_photometry.py", "bench_f32.py"):
         try:
-            p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script)], capture_output=True, text=True, timeout=300)
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script)], capture_output=True, text=True, timeout=400)
             for line in p.stdout.splitlines():
                 if line.startswith("{"):
                     j = json.loads(line)
@@ -479,6 +480,8 @@ def extras(a, torch, E, N, pflib, imgs, d_img, prm, dev):
                            "centroid_tracking_spot_frames_per_sec": "centroid_tracking_spot_frames_per_sec",
                            "mexican_hat_spots_per_sec": "photometry_spots_per_sec"}.get(j["metric"], j["metric"])
                     out[key] = j["value"]
+                    if script == "bench_f32.py" and "note" in j:
+                        out[key + "_note"] = j["note"]
             if p.returncode != 0:
                 out[script + "_error"] = p.stderr[-300:]
         except Exception as e:      # noqa: BLE001 - a side measurement must not take the headline down

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("FSQ_HIP_LIB") or os.path.join(HERE, "csrc", "libfsq_h
 
 FSQ_OK, FSQ_EINVAL, FSQ_ENOMEM, FSQ_ERANGE, FSQ_EHIP, FSQ_EASSERT, FSQ_ENOTIMPL, FSQ_EAGAIN = 0, -1, -2, -3, -4, -5, -6, -7
 MAX_TICKETS = 32
-MODE_REF, MODE_TEXTBOOK, ENGINE_LANE, ENGINE_QUAD = 0, 1, 0x100, 0x200
+MODE_REF, MODE_TEXTBOOK, MODE_TEXTBOOK_F32, ENGINE_LANE, ENGINE_QUAD = 0, 1, 2, 0x100, 0x200
 PIXELS_U16, PIXELS_F16, PIXELS_F16_FLAG = 0, 1, 0x1000
 DTYPE_F64, DTYPE_U16 = 0, 1
 

@@ -163,7 +163,8 @@ extern "C" int fsq_fit_candidates(const uint16_t* d_img, int n_fields, int H, in
                                   int mode, FsqRow* d_rows, void* d_workspace, int64_t workspace_bytes, void* stream)
 {
     const int m = mode & 0xff;
-    if (n < 0 || H < 5 || W < 5 || n_fields < 1 || (m != FSQ_MODE_REF && m != FSQ_MODE_TEXTBOOK)) return FSQ_EINVAL;
+    if (n < 0 || H < 5 || W < 5 || n_fields < 1 || (m != FSQ_MODE_REF && m != FSQ_MODE_TEXTBOOK && m != FSQ_MODE_TEXTBOOK_F32)) return FSQ_EINVAL;
+    if (m == FSQ_MODE_TEXTBOOK_F32 && (mode & (FSQ_ENGINE_LANE | FSQ_ENGINE_QUAD))) return FSQ_EINVAL;
     if (n == 0) return FSQ_OK;
     if (!d_img || !d_cand || !d_rows) return FSQ_EINVAL;
 #ifndef FSQ_BUILD_AB
@@ -184,7 +185,8 @@ extern "C" int fsq_fit_rois(const uint16_t* d_rois, int64_t n, int mode, FsqRow*
                             int64_t workspace_bytes, void* stream)
 {
     const int m = mode & 0xff;
-    if (n < 0 || (m != FSQ_MODE_REF && m != FSQ_MODE_TEXTBOOK)) return FSQ_EINVAL;
+    if (n < 0 || (m != FSQ_MODE_REF && m != FSQ_MODE_TEXTBOOK && m != FSQ_MODE_TEXTBOOK_F32)) return FSQ_EINVAL;
+    if (m == FSQ_MODE_TEXTBOOK_F32 && (mode & (FSQ_ENGINE_LANE | FSQ_ENGINE_QUAD))) return FSQ_EINVAL;
     if (n == 0) return FSQ_OK;
     if (!d_rois || !d_rows) return FSQ_EINVAL;
 #ifdef FSQ_BUILD_AB

@@ -116,6 +116,7 @@ struct BatchArgs {
     int pix_fmt;              // FSQ_PIXELS_U16 / FSQ_PIXELS_F16 (images only; stand-alone ROIs are uint16)
     long long base;           // first pool slot
     int ticket;
+    int no_queue;             // FSQ_MODE_TEXTBOOK_F32: kinit leaves the clipped start in out[slot].x instead of a queue-A record
 };
 
 // Count the lanes with `term` set into their batches' done counters: one atomic per wave per batch present.
@@ -200,7 +201,7 @@ __global__ void __launch_bounds__(256) kinit(Ctx c, BatchArgs b, double* __restr
     const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool ok = i0 < b.n;
     const long long i = ok ? i0 : 0;            // idle lanes of the last block recompute fit 0 and store nothing
-    const int pos = wave_reserve(cntA, ok);     // appended behind whatever the queue already holds
+    const int pos = wave_reserve(cntA, ok && !b.no_queue);     // appended behind whatever the queue already holds
     if (b.n <= 0) return;
     const long long slot = b.base + i;
     double v[FSQ_NPIX];
@@ -231,21 +232,32 @@ __global__ void __launch_bounds__(256) kinit(Ctx c, BatchArgs b, double* __restr
     const double vmedian = v[12], vmean = isum / 25.0;
     const double llim1 = (mx - vmean) / 3.0;                               // pflib.py:207-209
     double x0[FSQ_NP] = {vmedian, mx, 2.5, 2.5, 1., 1., 0.};               // pflib.py:201-202
-    const NtQ q = ntq(QA + pos);
-    const long long cap = c.cap;
+    c.stat[slot].vmax = mx; c.stat[slot].vmean = vmean;
 #pragma unroll
     for (int k = 0; k < FSQ_NP; k++) {                                     // gaussfitter.py:202-204
         double t = x0[k];
         if (t > fsq_ulim(k) && fsq_qulim(k)) t = fsq_ulim(k);
         if (t < fsq_llim(k, llim1)) t = fsq_llim(k, llim1);
-        q[(A_X + k) * cap] = t;
+        x0[k] = t;
+    }
+    if (b.no_queue) {
+#pragma unroll
+        for (int k = 0; k < FSQ_NP; k++) c.out[slot].x[k] = x0[k];
+        return;
+    }
+    const NtQ q = ntq(QA + pos);
+    const long long cap = c.cap;
+#pragma unroll
+    for (int k = 0; k < FSQ_NP; k++) {
+        q[(A_X + k) * cap] = x0[k];
         q[(A_DIAG + k) * cap] = 0.;
     }
     q[A_IDX * cap] = pack2((int)((unsigned)slot | ((unsigned)b.ticket << c.tshift)), 0);       // (second word: lmpar history, none yet)
     q[A_LLIM1 * cap] = llim1; q[A_FNORM * cap] = 0.; q[A_PAR * cap] = 0.; q[A_DELTA * cap] = 0.; q[A_XNORM * cap] = 0.;
     q[A_ITER * cap] = pack2(1, 0);                                         // niter = 1, nfev = 0  (nfev == 0 <=> fresh)
-    c.stat[slot].vmax = mx; c.stat[slot].vmean = vmean;
 }
+
+#include "fsq_fit_f32.h"
 
 // qrfac's norm down-dating squares a NumPy scalar, i.e. calls libm's pow(t, 2.0) (mpfit.py:1816) - a log, an exp, two
 // dependent table look-ups: a fifth of the Jacobian round's time for a number that is only ever COMPARED (pivot choice,
@@ -1427,7 +1439,7 @@ static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 // FsqFitQueue (include/fsq.h) keeps an engine alive across batches, so that the long latency-bound tail of one batch
 // (a fit may need 200 sequential iterations) rides along in the full launches of the batches submitted after it.
 namespace {
-enum { CTL_SLOW_TOTAL = 2 * CNT_SET, CTL_SLOW_CNT = 2 * CNT_SET + 1, CTL_DONE = 2 * CNT_SET + 8, CTL_INTS = CTL_DONE + FSQ_MAX_TICKETS };
+enum { CTL_SLOW_TOTAL = 2 * CNT_SET, CTL_SLOW_CNT = 2 * CNT_SET + 1, CTL_F32_NEXT = 2 * CNT_SET + 2, CTL_DONE = 2 * CNT_SET + 8, CTL_INTS = CTL_DONE + FSQ_MAX_TICKETS };
 
 struct RoundsCfg {
     int lm_first = FSQ_LMPAR_FIRST, lm_lo = FSQ_LMPAR_LO, sync_mask = 3, force_slow_mod = 0, force_redo = 0, no_wave_prio = 0, trace = 0;
@@ -1505,7 +1517,7 @@ struct FsqFitQueue {
     double *QA[2], *QB[2], *QC[2], *SQ = nullptr;
     int *cset[2], *cSlow = nullptr;
     RoundsCfg cfg;
-    bool ref = true, single_call = false;
+    bool ref = true, f32 = false, single_call = false;
     int cus = 256;
     long long round = 0;                                   // rounds run so far; set (round & 1) is consumed next
     long long boundA = 0, alive = 0, slow_pending = 0;     // host-side upper bounds: queue A of the current set, all fits in flight
@@ -1521,6 +1533,7 @@ struct FsqFitQueue {
         if (pool_ > 2000000000ull || qcap_ > 2000000000ull) return FSQ_ENOTIMPL;
         pool = pool_; qcap = qcap_; s = s_finish = stream; single_call = single;
         ref = ((mode & 0xff) == FSQ_MODE_REF);
+        f32 = ((mode & 0xff) == FSQ_MODE_TEXTBOOK_F32);
         cfg = read_cfg();
         unsigned char* ws = (unsigned char*)d_ws;
         ctl = (int*)ws;     // two sets of queue counters (CNT_*), slow total, slow queue, done counters per ticket
@@ -1575,16 +1588,25 @@ struct FsqFitQueue {
         for (int k = 0; k < FSQ_MAX_TICKETS; k++)
             if (b[k].state == T_FREE) { t = k; break; }
         if (t < 0) return FSQ_EAGAIN;
-        if ((size_t)(alive + n) > qcap) return FSQ_EAGAIN;
+        if (!f32 && (size_t)(alive + n) > qcap) return FSQ_EAGAIN;      // (the single-precision solver does not use the queues)
         const long long base = n > 0 ? alloc_slots(n) : 0;
         if (base < 0) return FSQ_EAGAIN;
         Batch& B = b[t];
         B.a.src = src; B.a.cand = cand; B.a.H = H; B.a.W = W; B.a.n = n; B.a.from_image = from_image ? 1 : 0; B.a.pix_fmt = pix_fmt;
-        B.a.base = base; B.a.ticket = t; B.rows = rows;
+        B.a.base = base; B.a.ticket = t; B.a.no_queue = f32 ? 1 : 0; B.rows = rows;
         if (!single_call && !B.ev) FSQ_HIP_CHECK(hipEventCreateWithFlags(&B.ev, hipEventDisableTiming));
         if (n == 0) {
             B.state = T_FINISHED;
             if (B.ev) FSQ_HIP_CHECK(hipEventRecord(B.ev, s));
+        } else if (f32) {
+            // single precision: no rounds - the whole batch is fitted by one persistent launch (fsq_fit_f32.h), in stream order
+            FSQ_HIP_CHECK(hipMemsetAsync(ctl + CTL_F32_NEXT, 0, sizeof(int), s));
+            hipLaunchKernelGGL(kinit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c, B.a, QA[0], cset[0] + CNT_A);
+            const long long waves = std::min<long long>((n + 63) / 64, (long long)cus * 12);          // 3 waves per SIMD (164 VGPRs)
+            hipLaunchKernelGGL(kfit_f32, dim3((unsigned)waves), dim3(64), 0, s, c, B.a, ctl + CTL_F32_NEXT);
+            hipLaunchKernelGGL(kfinish, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, c, B.a, rows);
+            if (B.ev) FSQ_HIP_CHECK(hipEventRecord(B.ev, s));
+            B.state = T_FINISHED;
         } else {
             const int cur = (int)(round & 1);
             FSQ_HIP_CHECK(hipMemsetAsync(c.done + t, 0, sizeof(int), s));
@@ -1740,7 +1762,7 @@ extern "C" int fsq_fitq_create(FsqFitQueue** out, void* d_workspace, int64_t wor
                                int64_t queue_cap, int mode, void* stream)
 {
     if (!out || pool_slots <= 0 || queue_cap <= 0) return FSQ_EINVAL;
-    if (mode & ~1) return FSQ_EINVAL;
+    if (mode != FSQ_MODE_REF && mode != FSQ_MODE_TEXTBOOK && mode != FSQ_MODE_TEXTBOOK_F32) return FSQ_EINVAL;
     FsqFitQueue* q = new (std::nothrow) FsqFitQueue();
     if (!q) return FSQ_ENOMEM;
     int rc = q->init(d_workspace, workspace_bytes, (size_t)pool_slots, (size_t)queue_cap, mode, (hipStream_t)stream, false);

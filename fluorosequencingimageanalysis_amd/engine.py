@@ -419,7 +419,9 @@ class StreamPipeline:
         if self.queue is not None:
             self.queue.close()
         self.cand_per_batch = per = int(per)
-        self.queue = FitQueue(pool_slots=min((self.depth + 2) * per, (1 << 27) - 1), queue_cap=2 * per + per // 2,
+        # (the single-precision solver runs no rounds: its queue holds the by-candidate pool only)
+        self.queue = FitQueue(pool_slots=min((self.depth + 2) * per, (1 << 27) - 1),
+                              queue_cap=64 if self.mode == N.MODE_TEXTBOOK_F32 else 2 * per + per // 2,
                               mode=self.mode, device=self.dev)
         self.inject_below = int(self._inject_below_arg if self._inject_below_arg is not None else per // 4)
 

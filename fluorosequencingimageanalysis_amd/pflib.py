@@ -204,12 +204,12 @@ class _BatchRunner:
     launches of the next), and their peak records are copied back and turned into dicts by a worker thread while the GPU
     works on the following chunks.  The object (pipeline workspaces, staging buffers) lives in the module cache between calls."""
 
-    def __init__(self, per, H, W):
+    def __init__(self, per, H, W, mode=N.MODE_REF):
         torch = _engine._torch()
         self.torch = torch
         self.per, self.H, self.W = int(per), int(H), int(W)
         self.dev = torch.device("cuda", torch.cuda.current_device())
-        self.pipe = _engine.StreamPipeline(self.per, H, W, depth=12, device=self.dev)
+        self.pipe = _engine.StreamPipeline(self.per, H, W, depth=12, device=self.dev, mode=mode)
         # four staging buffers: the stager runs at most two chunks ahead of the pipeline thread (queue of 2), so the buffer of
         # chunk c is written again (chunk c + 4) only after the pipeline thread has recorded the upload event of chunk c
         self.pin = [torch.empty((self.per, H, W), dtype=torch.int16).pin_memory() for _ in range(4)]
@@ -319,15 +319,29 @@ class _BatchRunner:
         return out[:n]
 
 
+SOLVERS = {"reference": N.MODE_REF, "textbook": N.MODE_TEXTBOOK, "textbook_f32": N.MODE_TEXTBOOK_F32}
+
+
+def _solver_mode(solver):
+    try:
+        return SOLVERS[solver]
+    except KeyError:
+        raise ValueError("solver must be one of %s" % ", ".join(sorted(SOLVERS)))
+
+
 def find_peptides_batch(images, median_filter_size=5, correlation_matrix=default_correlation_matrix,
                         candidate_pixels=None, c_std=2, r_2_threshold=0.7, consolidation_radius=4,
-                        fit_type='gauss', N_iter=10**3, engine=None, errors='raise', on_chunk=None):
+                        fit_type='gauss', N_iter=10**3, engine=None, errors='raise', on_chunk=None, solver='reference'):
     """find_peptides over a stack uint16[n, H, W] -> list of n dicts.
 
     The stack is streamed through the GPU in chunks of about CHUNK_PIXELS pixels (engine.StreamPipeline: continuous
     batching of the LM fits) by a _BatchRunner that stays alive between calls.  errors='return' puts the AssertionError of a
     field whose re-key collides (pflib.py:518) in that field's place instead of raising it.  on_chunk(first_index, dicts)
-    is called as soon as a chunk's dicts exist (from a worker thread)."""
+    is called as soon as a chunk's dicts exist (from a worker thread).
+    solver (an extension; the reference has one solver): 'reference' - mpfit as the reference runs it, bit for bit (default);
+    'textbook' - the same with MINPACK's qrsolv; 'textbook_f32' - the opt-in single-precision approximation of
+    BASELINE configs[4] (csrc/fsq_fit_f32.h: NOT the reference's numbers)."""
+    mode = _solver_mode(solver)
     if consolidation_radius < 2:
         raise ValueError("consolidation_radius must be at least 2")                # pflib.py:431-432
     if fit_type != 'gauss':
@@ -343,12 +357,12 @@ def find_peptides_batch(images, median_filter_size=5, correlation_matrix=default
         return []
     if engine is not None:                                  # (a caller-owned Engine: one stand-alone pass)
         d_img = _engine.to_device_u16(imgs)
-        engine.run(d_img, prm, r_2_threshold, consolidation_radius, N.MODE_REF, PY2_ROUND)
+        engine.run(d_img, prm, r_2_threshold, consolidation_radius, mode, PY2_ROUND)
         out = _engine_dicts(engine, d_img, fmt)
     else:
         n_chunks = max(1, -(-(n * H * W) // CHUNK_PIXELS))
         per = -(-n // n_chunks)
-        runner = _cached(("batch", _device_key(), per, H, W), lambda: _BatchRunner(per, H, W))
+        runner = _cached(("batch", _device_key(), per, H, W, mode), lambda: _BatchRunner(per, H, W, mode))
         out = runner.run(imgs, fmt, prm, r_2_threshold, consolidation_radius, on_chunk)
     if errors == 'raise':
         for d in out:
@@ -358,10 +372,11 @@ def find_peptides_batch(images, median_filter_size=5, correlation_matrix=default
 
 
 def find_peptides_records(images, median_filter_size=5, correlation_matrix=default_correlation_matrix, c_std=2,
-                          r_2_threshold=0.7, consolidation_radius=4, **unused):
+                          r_2_threshold=0.7, consolidation_radius=4, solver='reference', **unused):
     """find_peptides over a stack, results as the byte tables the multi-GPU gather ships instead of dicts:
     -> (records uint8[k, engine.PEAK_RECORD_BYTES] of all fields in order, int32[n] peaks per field (-1: the re-key
     assertion of pflib.py:518 fired for that field), pixel format).  records_to_dicts turns them into find_peptides' dicts."""
+    mode = _solver_mode(solver)
     if consolidation_radius < 2:
         raise ValueError("consolidation_radius must be at least 2")
     imgs, fmt = _engine.as_pixel_fields(images)
@@ -373,7 +388,7 @@ def find_peptides_records(images, median_filter_size=5, correlation_matrix=defau
         return np.zeros((0, _engine.PEAK_RECORD_BYTES), np.uint8), np.zeros(0, np.int32), fmt
     n_chunks = max(1, -(-(n * H * W) // CHUNK_PIXELS))
     per = -(-n // n_chunks)
-    runner = _cached(("batch", _device_key(), per, H, W), lambda: _BatchRunner(per, H, W))
+    runner = _cached(("batch", _device_key(), per, H, W, mode), lambda: _BatchRunner(per, H, W, mode))
     rec, counts = runner.run(imgs, fmt, prm, r_2_threshold, consolidation_radius, raw=True)
     return rec, counts, fmt
 

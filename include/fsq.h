@@ -35,6 +35,10 @@ extern "C" {
 
 #define FSQ_MODE_REF      0 /* reference-faithful fp64 LM (qrsolv/diag(R) aliasing of mpfit.py:1915) */
 #define FSQ_MODE_TEXTBOOK 1 /* same solver with MINPACK's diagonal restore */
+#define FSQ_MODE_TEXTBOOK_F32 2 /* OPT-IN approximation (BASELINE configs[4] "fp32 LM accumulate"): single-precision LM with an
+                                 analytic Jacobian and 7x7 normal equations, same model / start / bounds (gaussfitter.py:100-136,
+                                 pflib.py:199-212); results are NOT the reference's bit for bit - csrc/fsq_fit_f32.h, DESIGN.md 4.9.
+                                 R^2 / rmse / s_n of the row are still computed in fp64 from the fitted parameters */
 #define FSQ_PIXELS_F16_FLAG 0x1000 /* OR into mode (fsq_fit_candidates): d_img holds FSQ_PIXELS_F16 pixels */
 #define FSQ_ENGINE_LANE 0x100 /* OR into mode: persistent kernel, one GPU lane per fit (A/B timing only) */
 #define FSQ_ENGINE_QUAD 0x200 /* OR into mode: persistent kernel, a quad of lanes per fit (A/B timing only) */
@@ -97,7 +101,7 @@ int fsq_detect(const uint16_t* d_img, int n_fields, int H, int W, const FsqDetec
 int64_t fsq_fit_workspace_bytes(int64_t n);
 
 /* LM-fit n candidates (any mix of fields); d_rows[n] out.
- * mode: FSQ_MODE_REF / FSQ_MODE_TEXTBOOK.  The default engine advances all candidates in rounds
+ * mode: FSQ_MODE_REF / FSQ_MODE_TEXTBOOK (/ FSQ_MODE_TEXTBOOK_F32: one persistent launch, no rounds).  The default engine advances all candidates in rounds
  * (Jacobian round / step round, see csrc/fsq_fit_rounds.hip): the call drives those rounds from the calling
  * host thread and synchronises the stream every few rounds to read the queue sizes, so it returns when the
  * last round has run (large batches finish their last, nearly empty rounds on an internal highest-priority
@@ -131,7 +135,7 @@ int fsq_fit_candidates(const uint16_t* d_img, int n_fields, int H, int W, const 
 typedef struct FsqFitQueue FsqFitQueue;
 int64_t fsq_fitq_workspace_bytes(int64_t pool_slots, int64_t queue_cap);
 int fsq_fitq_create(FsqFitQueue** q, void* d_workspace, int64_t workspace_bytes, int64_t pool_slots, int64_t queue_cap,
-                    int mode /* FSQ_MODE_REF / FSQ_MODE_TEXTBOOK */, void* stream);
+                    int mode /* FSQ_MODE_REF / FSQ_MODE_TEXTBOOK / FSQ_MODE_TEXTBOOK_F32 */, void* stream);
 /* Add a batch (same arguments as fsq_fit_candidates; d_img / d_cand / d_rows must stay valid until the batch has been
  * taken).  Work enqueued on the queue's stream so far must not still be writing d_cand (order it with an event or
  * synchronise).  *ticket names the batch.  FSQ_EAGAIN: no free slots / tickets now. */
