@@ -320,11 +320,11 @@ def run_stream(a, torch, dist, D, E, N, d_img, imgs, prm, dev, rank, world):
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(Q)]
     r0 = [p.queue.rounds for p in group.pipes]
     for k in range(Q):
-        ev[k][0].record(group.pipes[k].queue.stream)
+        ev[k][0].record(group.pipes[k].fit_stream)
     t0 = time.perf_counter()
     totals = steps(a.steps)
     for k in range(Q):
-        ev[k][1].record(group.pipes[k].queue.stream)
+        ev[k][1].record(group.pipes[k].fit_stream)
     _barrier(torch, dist, world)
     dt = time.perf_counter() - t0
     busy_ms = max(ev[k][0].elapsed_time(ev[k][1]) for k in range(Q))        # the queues' streams are busy side by side
@@ -410,7 +410,7 @@ def extras(a, torch, E, N, pflib, imgs, d_img, prm, dev):
     def jobs(k):
         for j in range(k):
             b = bufs[j % 3]
-            torch.cuda.current_stream().wait_stream(pipe.queue.stream)   # kinit of the batch that used this buffer
+            torch.cuda.current_stream().wait_stream(pipe.fit_stream)   # kinit of the batch that used this buffer
             b.copy_(pinned, non_blocking=True)
             yield b, prm
 

@@ -407,11 +407,18 @@ class StreamPipeline:
         self.shared_ws = torch.empty(Engine.workspace_bytes(self.n_fields, self.H, self.W), dtype=torch.uint8, device=self.dev)
         self.engines = [Engine(self.n_fields, self.H, self.W, device=self.dev, cand_per_field=cand_per_field,
                                fit_workspace=False, shared_ws=self.shared_ws) for _ in range(self.depth)]
-        per = int(cand_per_batch or self.engines[0].cap)
         self.mode = mode
         self._inject_below_arg = inject_below
+        self.fit_stream = torch.cuda.Stream(device=self.dev)       # the fit queue's stream (kept when the queue is rebuilt larger)
         self.queue = None
-        self._make_queue(per)
+        self.cand_per_batch = 0
+        self.inject_below = int(inject_below or 0)
+        # The queue is sized from what the FIRST batch's detection finds (+ 25 %), not from the engines' worst-case candidate
+        # capacity (1 per 32 pixels): half the memory on bench.py's batches.  A later batch that does not fit waits until the
+        # queue is empty and gets a larger one (run()).  cand_per_batch fixes the size up front instead.
+        self.cand_per_batch_fixed = bool(cand_per_batch)
+        if cand_per_batch:
+            self._make_queue(int(cand_per_batch))
 
     def _make_queue(self, per):
         """(Re)build the fit queue for batches of up to `per` candidates.  A batch's pool slots are held until its last fit is
@@ -422,8 +429,10 @@ class StreamPipeline:
         # (the single-precision solver runs no rounds: its queue holds the by-candidate pool only)
         self.queue = FitQueue(pool_slots=min((self.depth + 2) * per, (1 << 27) - 1),
                               queue_cap=64 if self.mode == N.MODE_TEXTBOOK_F32 else 2 * per + per // 2,
-                              mode=self.mode, device=self.dev)
-        self.inject_below = int(self._inject_below_arg if self._inject_below_arg is not None else per // 4)
+                              mode=self.mode, device=self.dev, stream=self.fit_stream)
+        # (the injection threshold stays a quarter of the engines' candidate capacity, as tuned on bench.py's batches)
+        self.inject_below = int(self._inject_below_arg if self._inject_below_arg is not None else min(per, self.engines[0].cap) // 4
+                                if self.cand_per_batch_fixed else self.engines[0].cap // 4)
 
     def run(self, jobs, on_done=None, r2_threshold=0.7, radius=4, py2_round=True):
         """jobs: iterable of (d_img, detect_params).  on_done(job_index, engine, total) is called, in order of
@@ -448,6 +457,9 @@ class StreamPipeline:
                         eng = free.pop()
                         total = eng.detect(d_img, prm)          # (synchronises the side stream: the count is needed)
                         totals.append(total)
+                        if self.queue is None:
+                            self._make_queue(total + total // 4 + 1024)
+                            q = self.queue
                         pending = (j, eng, total, d_img, prm.pixel_format)
                 if pending is not None and (not inflight or q.alive < self.inject_below):
                     j, eng, total, d_img, fmt = pending
@@ -479,7 +491,8 @@ class StreamPipeline:
         return totals
 
     def close(self):
-        self.queue.close()
+        if self.queue is not None:
+            self.queue.close()
 
 
 class StreamPipelineGroup:
