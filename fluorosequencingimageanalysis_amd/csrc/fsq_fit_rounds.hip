@@ -1501,8 +1501,14 @@ static_assert((1 << FSQ_TICKET_BITS) == FSQ_MAX_TICKETS, "ticket bits");
 enum { T_FREE = 0, T_FLIGHT = 1, T_FINISHED = 2 };
 struct Batch { BatchArgs a; FsqRow* rows; int state; hipEvent_t ev; };
 
+// Queue capacity in positions: field f of the record at position i lives at q[f * cap + i], and a wave reads / writes 64
+// consecutive positions of a field at a time - with cap a multiple of 256 every such 512-byte piece is aligned, whatever
+// capacity the caller asked for (an odd cap measured 6 % slower: every access straddled one more cache line).
+size_t cap_round(size_t q) { return (q + 255) & ~(size_t)255; }
+
 size_t layout_bytes(size_t pool, size_t qcap)
 {
+    qcap = cap_round(qcap);
     size_t b = 4096;
     b += al256(pool * 64) + al256(pool * FSQ_NPIX * 8) + al256(pool * sizeof(FitOut)) + al256(pool * sizeof(FitStat));
     b += 2 * al256(qcap * A_LEN * 8) + 2 * al256(qcap * B_LEN * 8) + 2 * al256(qcap * C_LEN * 8) + al256(qcap * A_LEN * 8);
@@ -1530,6 +1536,7 @@ struct FsqFitQueue {
     int init(void* d_ws, int64_t ws_bytes, size_t pool_, size_t qcap_, int mode, hipStream_t stream, bool single)
     {
         if (!d_ws || (size_t)ws_bytes < layout_bytes(pool_, qcap_)) return FSQ_ENOMEM;
+        qcap_ = cap_round(qcap_);
         if (pool_ > 2000000000ull || qcap_ > 2000000000ull) return FSQ_ENOTIMPL;
         pool = pool_; qcap = qcap_; s = s_finish = stream; single_call = single;
         ref = ((mode & 0xff) == FSQ_MODE_REF);

@@ -383,6 +383,9 @@ class FitQueue:
             pass
 
 
+_ALLOC_LOCK = __import__("threading").Lock()
+
+
 class StreamPipeline:
     """detect -> LM fit -> consolidate over a STREAM of same-shaped batches with continuous batching of the fits.
 
@@ -410,6 +413,12 @@ class StreamPipeline:
         self.mode = mode
         self._inject_below_arg = inject_below
         self.fit_stream = torch.cuda.Stream(device=self.dev)       # the fit queue's stream (kept when the queue is rebuilt larger)
+        # HIP binds a stream to one of the few hardware queues when the stream is first USED, round robin; two streams on one
+        # hardware queue run their kernels one after the other.  Used here, right after its creation, the fit stream gets its
+        # hardware queue in creation order (two pipelines side by side: different ones) - bound later, behind the side
+        # streams' first detections, the two fit queues of bench.py shared one and lost their overlap (226 against 210 ms).
+        with torch.cuda.device(self.dev), torch.cuda.stream(self.fit_stream):
+            self._stream_pin = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.queue = None
         self.cand_per_batch = 0
         self.inject_below = int(inject_below or 0)
@@ -427,9 +436,12 @@ class StreamPipeline:
             self.queue.close()
         self.cand_per_batch = per = int(per)
         # (the single-precision solver runs no rounds: its queue holds the by-candidate pool only)
-        self.queue = FitQueue(pool_slots=min((self.depth + 2) * per, (1 << 27) - 1),
-                              queue_cap=64 if self.mode == N.MODE_TEXTBOOK_F32 else 2 * per + per // 2,
-                              mode=self.mode, device=self.dev, stream=self.fit_stream)
+        torch = self.torch
+        # (one allocation at a time, and not under the caller's side stream)
+        with _ALLOC_LOCK, torch.cuda.device(self.dev), torch.cuda.stream(torch.cuda.default_stream(self.dev)):
+            self.queue = FitQueue(pool_slots=min((self.depth + 2) * per, (1 << 27) - 1),
+                                  queue_cap=64 if self.mode == N.MODE_TEXTBOOK_F32 else 2 * per + per // 2,
+                                  mode=self.mode, device=self.dev, stream=self.fit_stream)
         # (the injection threshold stays a quarter of the engines' candidate capacity, as tuned on bench.py's batches)
         self.inject_below = int(self._inject_below_arg if self._inject_below_arg is not None else min(per, self.engines[0].cap) // 4
                                 if self.cand_per_batch_fixed else self.engines[0].cap // 4)
