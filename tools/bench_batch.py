@@ -1,5 +1,5 @@
 """fields/s of the dict-materialising pflib surface on host fields (what bench.py's extras report), plus a time split.
-usage: python3 tools/bench_batch.py [n_fields=1024] [size=512] [spots=500]"""
+usage: python3 tools/bench_batch.py [n_fields=1024] [size=512] [spots=500] [fields per chunk=128]"""
 import os
 import sys
 import time
@@ -16,6 +16,9 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     size = int(sys.argv[2]) if len(sys.argv) > 2 else 512
     spots = int(sys.argv[3]) if len(sys.argv) > 3 else 500
+    if len(sys.argv) > 4:
+        pflib.CHUNK_PIXELS = int(sys.argv[4]) * size * size
+        pflib.WINDOW_PIXELS = 8 * pflib.CHUNK_PIXELS
     imgs = bench.make_fields(range(1000, 1000 + n), (size, size), spots)
     pflib.find_peptides_batch(imgs[:256])
     for rep in range(3):

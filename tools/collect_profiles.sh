@@ -13,6 +13,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats_q1 -
 echo "stats done"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats_cfg3 -- $B --config 3 --steps 10 --warmup 2 > gpurun_out/$R/bench_stats_cfg3.log 2>&1
 echo "cfg3 stats done"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats_f32 -- python3 tools/bench_f32.py 1024 4 > gpurun_out/$R/bench_stats_f32.log 2>&1
+echo "f32 stats done"
 # counters with ONE fit queue: kernels of a single stream do not overlap, so per-kernel durations add up to busy time
 S="--steps 2 --warmup 0 --fields 256 --queues 1"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/$R/pmc_fetch -- $B $S > gpurun_out/$R/bench_fetch.log 2>&1

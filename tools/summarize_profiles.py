@@ -25,7 +25,10 @@ for tag, title, steps in (("stats", "python3 bench.py --steps 6 --warmup 1 (the 
                            "Kernels of the two queues run CONCURRENTLY: their durations overlap and add up to more than wall time", 8),
                           ("stats_q1", "python3 bench.py --steps 6 --warmup 1 --queues 1 (one fit queue: kernels run one after the other, "
                            "durations add up to busy time)", 8),
-                          ("stats_cfg3", "python3 bench.py --config 3 --steps 10 --warmup 2 (1 + 2 + 10 = 13 registration calls)", 13)):
+                          ("stats_cfg3", "python3 bench.py --config 3 --steps 10 --warmup 2 (1 + 2 + 10 = 13 registration calls)", 13),
+                          ("stats_f32", "python3 tools/bench_f32.py 1024 4 (the opt-in single-precision solver, FSQ_MODE_TEXTBOOK_F32: kfit_f32 is "
+                           "launched once per batch of candidates - 1 024-field batches of 4.36 M fits, then 64- and 32-field batches; kA / kB rows "
+                           "are the fp64 textbook runs it is compared with)", 1)):
     f = sorted(glob.glob(base + "/%s/*/*kernel_stats.csv" % tag))
     if not f:
         continue
@@ -45,6 +48,11 @@ for tag, title, steps in (("stats", "python3 bench.py --steps 6 --warmup 1 (the 
         out["all_kernels_ms_per_step_" + tag] = allk / steps
         md += ["", "LM fit (kinit + every kA_jacobian / kB_step round + kfinish): %.1f ms of kernel time per step; all kernels %.1f ms per step "
                "(detection and consolidation run on a second stream, concurrently with the rounds)." % (fit / steps, allk / steps), ""]
+    elif tag == "stats_f32":
+        for r in rows:
+            if "kfit_f32" in r["Name"]:
+                out["kfit_f32_max_ms"] = float(r["MaxNs"]) / 1e6
+                md += ["", "kfit_f32: longest launch %.2f ms (a 1 024-field batch of 4.36 M fits), %s launches in all." % (float(r["MaxNs"]) / 1e6, r["Calls"]), ""]
     else:
         tot = sum(float(r["TotalDurationNs"]) for r in rows) / 1e6
         out["registration_kernels_ms_per_call"] = tot / steps
