@@ -10,7 +10,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FSQ_HIP_LIB") or os.path.join(HERE, "csrc", "libfsq_hip.so")   # env: A/B builds
 
-FSQ_OK, FSQ_EINVAL, FSQ_ENOMEM, FSQ_ERANGE, FSQ_EHIP, FSQ_EASSERT, FSQ_ENOTIMPL, FSQ_EAGAIN = 0, -1, -2, -3, -4, -5, -6, -7
+FSQ_OK, FSQ_EINVAL, FSQ_ENOMEM, FSQ_ERANGE, FSQ_EHIP, FSQ_EASSERT, FSQ_ENOTIMPL, FSQ_EAGAIN, FSQ_EINTERNAL = 0, -1, -2, -3, -4, -5, -6, -7, -8
 MAX_TICKETS = 32
 MODE_REF, MODE_TEXTBOOK, MODE_TEXTBOOK_F32, ENGINE_LANE, ENGINE_QUAD = 0, 1, 2, 0x100, 0x200
 PIXELS_U16, PIXELS_F16, PIXELS_F16_FLAG = 0, 1, 0x1000
@@ -143,4 +143,6 @@ def check(rc, what):
         raise BlockingIOError("%s: the fit queue has no room right now" % what)
     if rc == FSQ_EHIP:
         raise RuntimeError("%s: HIP error: %s" % (what, lib().fsq_last_hip_error().decode()))
+    if rc == FSQ_EINTERNAL:
+        raise RuntimeError("%s: the fit queue is empty but a batch is incomplete (engine bug)" % what)
     raise RuntimeError("%s: error %d" % (what, rc))

@@ -1634,20 +1634,23 @@ struct FsqFitQueue {
         // between them.
         const int G = 64 / cfg.ka_lanes;
         const long long gA = (boundA + G - 1) / G;
+        if (slow_pending > 0) {
+            // fits that left the guarded operand ranges in EARLIER rounds: the plain-division build takes them from the slow
+            // queue (whatever it holds by now - it may have grown since the host looked) and appends their queue-B records to
+            // this round's.  It runs BEFORE this round's fast kernel: a fit the fast kernel sends to the slow queue has already
+            // reserved a (dead) queue-B slot in this round, and worked off in the same round it would take a second one - the
+            // step round's grid is sized for one slot per live fit, and tiles beyond it would never run (a lost fit, a batch
+            // that never finishes; found by the round-3 fuzz on noise fields, where hundreds of fits take this path at once).
+            hipLaunchKernelGGL((kA_jacobian<false, 4>), dim3((unsigned)std::min<long long>((alive + 15) / 16, (long long)cus * 8)), dim3(64), 0, s, c, SQ, cSlow, QB[cur], cset[cur], SQ, cSlow, cset[nxt]);
+            FSQ_HIP_CHECK(hipMemsetAsync(cSlow, 0, sizeof(int), s));
+            slow_pending = 0;
+        }
         if (gA > 0 && cfg.ka_lanes == 8)            // (kA also zeroes the counters of set nxt)
             hipLaunchKernelGGL((kA_jacobian<true, 8>), dim3((unsigned)gA), dim3(64), cfg.ka_lds_pad, s, c, QA[cur], cset[cur] + CNT_A, QB[cur], cset[cur], SQ, cSlow, cset[nxt]);
         else if (gA > 0)
             hipLaunchKernelGGL((kA_jacobian<true, 4>), dim3((unsigned)gA), dim3(64), cfg.ka_lds_pad, s, c, QA[cur], cset[cur] + CNT_A, QB[cur], cset[cur], SQ, cSlow, cset[nxt]);
         else
             FSQ_HIP_CHECK(hipMemsetAsync(cset[nxt], 0, CNT_SET * sizeof(int), s));
-        if (slow_pending > 0) {
-            // fits that left the guarded operand ranges since the host last looked: the plain-division build takes them
-            // from the slow queue and appends their queue-B records to this round's (the slow queue may have grown since the
-            // host looked: the kernel strides over whatever it finds)
-            hipLaunchKernelGGL((kA_jacobian<false, 4>), dim3((unsigned)std::min<long long>((alive + 15) / 16, (long long)cus * 8)), dim3(64), 0, s, c, SQ, cSlow, QB[cur], cset[cur], SQ, cSlow, cset[nxt]);
-            FSQ_HIP_CHECK(hipMemsetAsync(cSlow, 0, sizeof(int), s));
-            slow_pending = 0;
-        }
         // every fit in flight is in one of the four input lists of the step round by now (or terminated, or in the slow queue)
         const long long gB = (alive + 63) / 64 + 4;
         {
@@ -1714,6 +1717,20 @@ struct FsqFitQueue {
             if (round > 100000000ll) return FSQ_EHIP;
         }
         FSQ_HIP_CHECK(hipGetLastError());
+        if (alive == 0 && fin_total == 0) {
+            // nothing is alive, so every batch in flight must be complete; one that is not has lost a fit (an engine bug): say so
+            // instead of letting the caller wait for it for ever
+            bool flight = false;
+            for (const auto& t : b) flight = flight || (t.state == T_FLIGHT);
+            if (flight) {
+                int fin = 0;
+                const int rc = look(&fin);
+                if (rc != FSQ_OK) return rc;
+                fin_total += fin;
+                for (const auto& t : b)
+                    if (t.state == T_FLIGHT && alive == 0) return FSQ_EINTERNAL;
+            }
+        }
         if (alive_out) *alive_out = alive;
         if (finished_out) *finished_out = fin_total;
         return FSQ_OK;

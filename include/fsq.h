@@ -32,6 +32,7 @@ extern "C" {
 #define FSQ_EASSERT  (-5)   /* the reference's assert at pflib.py:518 would fire */
 #define FSQ_ENOTIMPL (-6)   /* reference raises NotImplementedError (pflib.py:195) */
 #define FSQ_EAGAIN   (-7)   /* FsqFitQueue: no room for the batch right now - advance the queue and submit again */
+#define FSQ_EINTERNAL (-8)  /* FsqFitQueue: no fit is alive but a batch is incomplete - an engine bug, reported instead of waiting for ever */
 
 #define FSQ_MODE_REF      0 /* reference-faithful fp64 LM (qrsolv/diag(R) aliasing of mpfit.py:1915) */
 #define FSQ_MODE_TEXTBOOK 1 /* same solver with MINPACK's diagonal restore */

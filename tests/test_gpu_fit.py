@@ -192,6 +192,31 @@ def test_plain_division_kernel_gives_the_same_fits(env, monkeypatch):
     assert got2.tobytes() == got.tobytes()
 
 
+def test_every_fit_through_the_slow_queue(env, monkeypatch):
+    """All fits leave the fast path in every Jacobian round (FSQ_DEBUG_FORCE_SLOW=1) - as many slow-queue entries per round as
+    there are live fits.  Round 3's fuzz found noise fields on which hundreds of fits took that path at once and one was
+    lost (the step round's grid is sized for one queue slot per live fit; a fit worked off by the plain-division kernel in
+    the round in which the fast kernel had already reserved it a slot took two): the batch must finish, with the oracle's
+    bits, stand-alone and streamed."""
+    torch, N, O = env
+    from fluorosequencingimageanalysis_amd import engine as E, pflib
+    g, img = load_field("f5_small_96")
+    rois = rois_of(img, g["candidates"])
+    monkeypatch.setenv("FSQ_DEBUG_FORCE_SLOW", "1")
+    got = gpu_fit_rois(torch, N, np.tile(rois, (40, 1)))                    # 4 520 fits: 70 step-round tiles, every one doubled
+    assert N.lib().fsq_fit_last_slow_count() >= len(got)
+    p = np.stack([got[k] for k in ("H", "A", "p2", "p3", "sigma_h", "sigma_w", "theta")], axis=1)
+    assert bits_equal(p, np.tile(g["params"], (40, 1))).all() and np.array_equal(got["status"], np.tile(g["status"], 40))
+    imgs = np.stack([img] * 24)
+    prm = E.detect_params(5, pflib.default_correlation_matrix, 2)
+    pipe = E.StreamPipeline(8, img.shape[0], img.shape[1], depth=3)
+    seen = []
+    pipe.run([(E.to_device_u16(imgs[i:i + 8]), prm) for i in range(0, 24, 8)], lambda j, eng, total: seen.append((j, int(eng.nkeep[8].item()))))
+    pipe.close()
+    monkeypatch.delenv("FSQ_DEBUG_FORCE_SLOW")
+    assert sorted(seen) == [(j, 8 * len(g["table_keys"])) for j in range(3)]
+
+
 def test_square_shortcut_equals_pow(env):
     """qrfac's norm down-dating squares a NumPy scalar, i.e. libm's pow(t, 2.0) (mpfit.py:1816); the Jacobian kernel takes
     t * t wherever fsq_square_is_pow2 holds.  The implication `predicate => pow(t, 2.0) == t * t` on: the ratios the
