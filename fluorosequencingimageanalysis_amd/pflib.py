@@ -78,6 +78,8 @@ def _psf_candidates(image, median_filter_size=5, correlation_matrix=default_corr
     if img.ndim != 2:
         raise ValueError("image must be two-dimensional")
     H, W = img.shape
+    if H < 5 or W < 5:              # no pixel has a 5x5 neighbourhood: the reference's loop over range(2, H - 2) is empty (pflib.py:252)
+        return []
     eng = _cached(("detect", _device_key(), H, W), lambda: _engine.Engine(1, H, W, fit_workspace=False))
     with _CACHE_LOCK:
         total = eng.detect(_engine.to_device_u16(img), prm)
@@ -355,6 +357,8 @@ def find_peptides_batch(images, median_filter_size=5, correlation_matrix=default
     n, H, W = imgs.shape
     if n == 0:
         return []
+    if H < 5 or W < 5:              # (no candidates: pflib.py:252)
+        return [{} for _ in range(n)]
     if engine is not None:                                  # (a caller-owned Engine: one stand-alone pass)
         d_img = _engine.to_device_u16(imgs)
         engine.run(d_img, prm, r_2_threshold, consolidation_radius, mode, PY2_ROUND)
@@ -384,8 +388,8 @@ def find_peptides_records(images, median_filter_size=5, correlation_matrix=defau
     if imgs.ndim != 3:
         raise ValueError("images must have shape (n, H, W)")
     n, H, W = imgs.shape
-    if n == 0:
-        return np.zeros((0, _engine.PEAK_RECORD_BYTES), np.uint8), np.zeros(0, np.int32), fmt
+    if n == 0 or H < 5 or W < 5:
+        return np.zeros((0, _engine.PEAK_RECORD_BYTES), np.uint8), np.zeros(n, np.int32), fmt
     n_chunks = max(1, -(-(n * H * W) // CHUNK_PIXELS))
     per = -(-n // n_chunks)
     runner = _cached(("batch", _device_key(), per, H, W, mode), lambda: _BatchRunner(per, H, W, mode))
@@ -409,8 +413,8 @@ def count_candidates(images, median_filter_size=5, correlation_matrix=default_co
     if imgs.ndim != 3:
         raise ValueError("images must have shape (n, H, W)")
     n, H, W = imgs.shape
-    if n == 0:
-        return np.zeros(0, np.int64)
+    if n == 0 or H < 5 or W < 5:
+        return np.zeros(n, np.int64)
     eng = _cached(("count", _device_key(), n, H, W), lambda: _engine.Engine(n, H, W, fit_workspace=False))
     with _CACHE_LOCK:
         eng.detect(_engine.to_device_u16(imgs), prm)

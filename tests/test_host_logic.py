@@ -83,6 +83,15 @@ def test_parameter_validation_without_gpu():
     assert pflib.illumina_s_n(np.arange(25).reshape(5, 5)) == (24 - np.mean([0, 1, 2, 3, 4, 20, 21, 22, 23, 24, 5, 9, 10, 14, 15, 19])) / np.std([0, 1, 2, 3, 4, 20, 21, 22, 23, 24, 5, 9, 10, 14, 15, 19])
     with pytest.raises(ValueError):
         pflib.illumina_s_n(np.zeros((4, 5)))
+    # an image without a single 5x5 neighbourhood has no candidates (the reference's loop over range(2, H - 2), pflib.py:252,
+    # is empty): empty results, no GPU involved
+    for shape in ((1, 1), (4, 100), (100, 4), (2, 7)):
+        tiny = np.ones(shape, np.uint16)
+        assert pflib.find_peptides(tiny) == {} and pflib._psf_candidates(tiny) == []
+        assert pflib.find_peptides_batch(np.stack([tiny] * 3)) == [{}, {}, {}]
+        assert pflib.count_candidates(np.stack([tiny] * 2)).tolist() == [0, 0]
+        rec, counts, _ = pflib.find_peptides_records(np.stack([tiny] * 2))
+        assert rec.shape == (0, engine.PEAK_RECORD_BYTES) and counts.tolist() == [0, 0] and pflib.records_to_dicts(rec, counts) == [{}, {}]
 
 
 def test_product_does_not_import_oracle():
