@@ -607,7 +607,7 @@ WINDOW_PIXELS = 8 * CHUNK_PIXELS
 # (multiprocessing.Pool, pflib.py:1082-1099); here the GPU work stays in this process and the workers do the file work:
 # read_image before, save_psfs_* after.  They are spawned (never forked: this process may have initialised the GPU) and
 # import nothing that touches the GPU.
-IO_WORKERS = None               # None: min(8, half the cores); 0: everything in this process
+IO_WORKERS = None               # None: min(12, half the cores); 0: everything in this process
 _IO_POOL = {"pool": None, "n": 0}
 IO_POOL_MIN_IMAGES = 16         # lists shorter than this are not worth starting the workers for
 
@@ -667,7 +667,7 @@ class _IoPool:
 
 
 def _io_pool(n_images, num_processes=None):
-    n = IO_WORKERS if IO_WORKERS is not None else min(8, max(1, (os.cpu_count() or 2) // 2))
+    n = IO_WORKERS if IO_WORKERS is not None else min(12, max(1, (os.cpu_count() or 2) // 2))
     if num_processes is not None:
         n = int(num_processes)
     if n <= 0 or n_images < IO_POOL_MIN_IMAGES:
