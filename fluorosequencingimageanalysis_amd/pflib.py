@@ -200,6 +200,20 @@ CHUNK_PIXELS = 128 * 512 * 512
 MAX_PIXELS_PER_PASS = 1024 * 512 * 512
 
 
+class _RunnerClosed(Exception):
+    pass
+
+
+def _run_cached_runner(key, factory, *args, **kw):
+    """runner.run(...) on the cached runner of `key`; a runner another thread's call has just evicted (and closed) is replaced."""
+    while True:
+        runner = _cached(key, factory)
+        try:
+            return runner.run(*args, **kw)
+        except _RunnerClosed:
+            continue
+
+
 class _BatchRunner:
     """find_peptides over a stack of same-shaped fields: chunks of `per` fields are uploaded through pinned staging buffers,
     streamed through a StreamPipeline (continuous batching of the LM fits: the slow fits of one chunk finish inside the round
@@ -218,9 +232,14 @@ class _BatchRunner:
         self.pin_ev = [None] * 4
         self.rec_pin = None                     # pinned landing buffer of the peak records (dict-building calls)
         self.lock = threading.Lock()
+        self.closed = False
 
     def close(self):
-        self.pipe.close()
+        """(called by the cache when it evicts the runner; waits for a call that is using it)"""
+        with self.lock:
+            if not self.closed:
+                self.closed = True
+                self.pipe.close()
 
     def run(self, words, fmt, prm, r_2_threshold, radius, on_chunk=None, raw=False):
         """words: uint16[n, H, W] (host).  -> list of n dicts / AssertionError instances.  on_chunk(first, dicts), if given, is
@@ -292,6 +311,9 @@ class _BatchRunner:
             futures.append(pool.submit(materialise, c, rec, offs, nk, ev))
 
         with self.lock:
+            if self.closed:                 # evicted from the cache by another thread between look-up and call: the caller fetches a new one
+                pool.shutdown(wait=False)
+                raise _RunnerClosed()
             stager = threading.Thread(target=stage, daemon=True)
             # (the pipeline thread needs the interpreter for a few calls per chunk; while the worker builds dicts it would
             # wait a whole switch interval - 5 ms by default - for each of them)
@@ -366,8 +388,8 @@ def find_peptides_batch(images, median_filter_size=5, correlation_matrix=default
     else:
         n_chunks = max(1, -(-(n * H * W) // CHUNK_PIXELS))
         per = -(-n // n_chunks)
-        runner = _cached(("batch", _device_key(), per, H, W, mode), lambda: _BatchRunner(per, H, W, mode))
-        out = runner.run(imgs, fmt, prm, r_2_threshold, consolidation_radius, on_chunk)
+        out = _run_cached_runner(("batch", _device_key(), per, H, W, mode), lambda: _BatchRunner(per, H, W, mode),
+                                 imgs, fmt, prm, r_2_threshold, consolidation_radius, on_chunk)
     if errors == 'raise':
         for d in out:
             if isinstance(d, Exception):
@@ -392,8 +414,8 @@ def find_peptides_records(images, median_filter_size=5, correlation_matrix=defau
         return np.zeros((0, _engine.PEAK_RECORD_BYTES), np.uint8), np.zeros(n, np.int32), fmt
     n_chunks = max(1, -(-(n * H * W) // CHUNK_PIXELS))
     per = -(-n // n_chunks)
-    runner = _cached(("batch", _device_key(), per, H, W, mode), lambda: _BatchRunner(per, H, W, mode))
-    rec, counts = runner.run(imgs, fmt, prm, r_2_threshold, consolidation_radius, raw=True)
+    rec, counts = _run_cached_runner(("batch", _device_key(), per, H, W, mode), lambda: _BatchRunner(per, H, W, mode),
+                                     imgs, fmt, prm, r_2_threshold, consolidation_radius, raw=True)
     return rec, counts, fmt
 
 

@@ -119,3 +119,36 @@ def test_fit_2d_gaussian_surface(env):
     assert [float(x) for x in r[:7]] == [p[2], p[3], p[0], p[1], p[4], p[5], p[6]]
     assert bits_equal(r[7], O.model(p)).all()
     assert pflib.illumina_s_n(sub) == O.illumina_s_n(sub)
+
+
+def test_concurrent_calls_and_cache_eviction():
+    """Three threads call find_peptides_batch on five stack shapes in different orders (more shapes than the resource cache
+    holds, so runners are evicted - closed - while other threads are mid-call or about to call): every result equals the
+    single-threaded one."""
+    import threading
+    from fluorosequencingimageanalysis_amd import pflib, synth
+    shapes = [(48, 48), (64, 40), (40, 72), (56, 56), (80, 48)]
+    stacks = [np.stack([synth.make_field(700 + 10 * k + i, s, 6 + i) for i in range(3)]) for k, s in enumerate(shapes)]
+    want = [pflib.find_peptides_batch(st) for st in stacks]
+    errs = []
+
+    def same(a, b):
+        return len(a) == len(b) and all(list(x) == list(y) and all(np.array_equal(np.asarray(u), np.asarray(v), equal_nan=True)
+                                                                    for k in x for u, v in zip(x[k], y[k])) for x, y in zip(a, b))
+
+    def work(order):
+        try:
+            for rep in range(3):
+                for k in order:
+                    if not same(pflib.find_peptides_batch(stacks[k]), want[k]):
+                        errs.append("shape %s differs" % (shapes[k],))
+        except Exception as e:      # noqa: BLE001 - reported below
+            errs.append(repr(e))
+
+    ths = [threading.Thread(target=work, args=(o,)) for o in ([0, 1, 2, 3, 4], [4, 3, 2, 1, 0], [2, 0, 4, 1, 3])]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=600)
+        assert not t.is_alive()
+    assert not errs, errs[:3]
