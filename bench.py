@@ -437,13 +437,13 @@ def extras(a, torch, E, N, pflib, imgs, d_img, prm, dev):
         best = dt if best is None else min(best, dt)
     out["find_peptides_batch_fields_per_sec"] = len(imgs) / best
     out["find_peptides_batch_note"] = ("pflib.find_peptides_batch on %d host fields -> list of dicts of 12-tuples (pinned H2D, chunks "
-                                       "of %d fields streamed through a cached pipeline, D2H, dicts built by a worker thread; "
-                                       "%d peaks)" % (len(imgs), pflib.CHUNK_PIXELS // (a.size * a.size), npk))
+                                       "of %d fields fitted by stand-alone passes in 3 lanes, D2H, dicts built by a worker thread "
+                                       "while the next chunks are fitted; %d peaks)" % (len(imgs), pflib.CHUNK_PIXELS // (a.size * a.size), npk))
     t0 = time.perf_counter()
     rec, counts, _fmt = pflib.find_peptides_records(imgs)
     dt = time.perf_counter() - t0
     out["find_peptides_records_fields_per_sec"] = len(imgs) / dt
-    out["find_peptides_records_note"] = "the same call returning the peak records as byte tables (no Python objects per peak)"
+    out["find_peptides_records_note"] = "the same stack through the continuous-batching pipeline, returned as byte tables (no Python objects per peak)"
     # the command line end to end: a directory of 16-bit TIFFs -> pickle + CSV per image
     m = min(256, len(imgs))
     tmp = tempfile.mkdtemp(prefix="fsq_bench_cli_")

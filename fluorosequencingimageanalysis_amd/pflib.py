@@ -214,22 +214,36 @@ def _run_cached_runner(key, factory, *args, **kw):
             continue
 
 
+#: stand-alone passes side by side when find_peptides_batch builds dicts (see _BatchRunner)
+DICT_LANES = 3
+
+
 class _BatchRunner:
     """find_peptides over a stack of same-shaped fields: chunks of `per` fields are uploaded through pinned staging buffers,
-    streamed through a StreamPipeline (continuous batching of the LM fits: the slow fits of one chunk finish inside the round
-    launches of the next), and their peak records are copied back and turned into dicts by a worker thread while the GPU
-    works on the following chunks.  The object (pipeline workspaces, staging buffers) lives in the module cache between calls."""
+    fitted, and their peak records are copied back and turned into dicts by a worker thread while the GPU works on the following
+    chunks.  The object (workspaces, staging buffers) lives in the module cache between calls.
+    Two ways through the GPU.  Record tables (raw=True) and the single-precision solver: engine.StreamPipeline - continuous
+    batching, the slow fits of one chunk finish inside the round launches of the next; fastest for the GPU, but every chunk
+    holds a few fits that run to maxiter, so ALL chunks of a call complete together at the very end.  Dicts: DICT_LANES
+    stand-alone passes side by side (each lane its own Engine, stream and thread, a chunk complete when its own slowest fit is):
+    ~10 % slower on the GPU, but the chunks complete evenly spaced, and the 0.23 s the interpreter needs to build 490 000
+    12-tuples overlap the fitting instead of following it (1 024 fields: 0.60 s -> 0.45 s)."""
 
     def __init__(self, per, H, W, mode=N.MODE_REF):
         torch = _engine._torch()
         self.torch = torch
         self.per, self.H, self.W = int(per), int(H), int(W)
         self.dev = torch.device("cuda", torch.cuda.current_device())
-        self.pipe = _engine.StreamPipeline(self.per, H, W, depth=12, device=self.dev, mode=mode)
+        self.mode = mode
+        self.pipe = None                        # (both built on first use)
+        self.lane_engines = self.lane_streams = None
         # four staging buffers: the stager runs at most two chunks ahead of the pipeline thread (queue of 2), so the buffer of
         # chunk c is written again (chunk c + 4) only after the pipeline thread has recorded the upload event of chunk c
         self.pin = [torch.empty((self.per, H, W), dtype=torch.int16).pin_memory() for _ in range(4)]
         self.pin_ev = [None] * 4
+        self.pin_free = [threading.Event() for _ in range(4)]   # set: the chunk staged in the buffer has been handed to the GPU
+        for e in self.pin_free:
+            e.set()
         self.rec_pin = None                     # pinned landing buffer of the peak records (dict-building calls)
         self.lock = threading.Lock()
         self.closed = False
@@ -239,7 +253,8 @@ class _BatchRunner:
         with self.lock:
             if not self.closed:
                 self.closed = True
-                self.pipe.close()
+                if self.pipe is not None:
+                    self.pipe.close()
 
     def run(self, words, fmt, prm, r_2_threshold, radius, on_chunk=None, raw=False):
         """words: uint16[n, H, W] (host).  -> list of n dicts / AssertionError instances.  on_chunk(first, dicts), if given, is
@@ -249,6 +264,7 @@ class _BatchRunner:
         import queue as _queue
         import sys
         torch, per = self.torch, self.per
+        n_lanes = 0 if (raw or self.mode == N.MODE_TEXTBOOK_F32) else int(os.environ.get("FSQ_BATCH_LANES", DICT_LANES))
         n = len(words)
         n_chunks = -(-n // per)
         out = [None] * (n_chunks * per)
@@ -257,18 +273,64 @@ class _BatchRunner:
         futures = []
         staged = _queue.Queue(maxsize=2)
 
+        def run_lanes():
+            """Stand-alone passes instead of the continuous-batching pipeline: every lane (its own Engine, stream and thread) takes
+            the next staged chunk, runs detect -> fit -> consolidate on it and hands its peak records to the worker.  A chunk is
+            complete when its own slowest fit is, so the chunks finish evenly spaced in time and the worker builds the dicts of
+            one while the lanes fit the next."""
+            errs = []
+
+            def body(k):
+                try:
+                    torch.cuda.set_device(self.dev)
+                    eng = self.lane_engines[k]
+                    with torch.cuda.stream(self.lane_streams[k]):
+                        while True:
+                            item = staged.get()
+                            if item is None or isinstance(item, BaseException):
+                                staged.put(item)            # (the end marker / the stager's error is for every lane)
+                                if isinstance(item, BaseException):
+                                    raise item
+                                return
+                            c, i = item
+                            d = self.pin[i].to(self.dev, non_blocking=True)
+                            self.pin_ev[i] = torch.cuda.Event()
+                            self.pin_ev[i].record()
+                            self.pin_free[i].set()
+                            eng.run(d, prm, r_2_threshold, radius, self.mode, PY2_ROUND)
+                            rec, offs = eng.peak_records(d)
+                            nk = eng.nkeep[:per].clone()
+                            ev = torch.cuda.Event()
+                            ev.record()
+                            futures.append(pool.submit(materialise, c, rec, offs, nk, ev))
+                        self.lane_streams[k].synchronize()
+                except BaseException as e:      # noqa: BLE001 - re-raised by the caller
+                    errs.append(e)
+
+            ths = [threading.Thread(target=body, args=(k,), daemon=True) for k in range(n_lanes)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            if errs:
+                raise errs[0]
+
         def stage():        # (own thread) copies the chunks into the pinned staging buffers ahead of the pipeline
             try:
                 for c in range(n_chunks):
                     part = words[c * per:(c + 1) * per]
                     i = c % 4
+                    self.pin_free[i].wait()                 # (the consumer of the chunk last staged here has issued its upload ...)
+                    self.pin_free[i].clear()
                     if self.pin_ev[i] is not None:
-                        self.pin_ev[i].synchronize()        # the upload that last used this staging buffer
+                        self.pin_ev[i].synchronize()        # (... and the upload is done)
                     host = self.pin[i].numpy().view(np.uint16)
                     host[:len(part)] = part
                     if len(part) < per:                     # the last chunk is filled up with copies of its last field
                         host[len(part):] = part[-1]
-                    staged.put(i)
+                    staged.put((c, i) if n_lanes > 0 else i)
+                if n_lanes > 0:
+                    staged.put(None)
             except BaseException as e:      # noqa: BLE001 - handed to the pipeline thread
                 staged.put(e)
 
@@ -280,6 +342,7 @@ class _BatchRunner:
                 bufs[c] = self.pin[i].to(self.dev, non_blocking=True)
                 self.pin_ev[i] = torch.cuda.Event()
                 self.pin_ev[i].record()
+                self.pin_free[i].set()
                 yield bufs[c], prm
 
         def materialise(c, rec, offs, nk, ev):
@@ -314,6 +377,13 @@ class _BatchRunner:
             if self.closed:                 # evicted from the cache by another thread between look-up and call: the caller fetches a new one
                 pool.shutdown(wait=False)
                 raise _RunnerClosed()
+            for e in self.pin_free:         # (a call that failed may have left a buffer marked busy)
+                e.set()
+            if n_lanes > 0 and (self.lane_engines is None or len(self.lane_engines) != n_lanes):
+                self.lane_engines = [_engine.Engine(self.per, self.H, self.W, device=self.dev) for _ in range(n_lanes)]
+                self.lane_streams = [torch.cuda.Stream(device=self.dev) for _ in range(n_lanes)]
+            if n_lanes == 0 and self.pipe is None:
+                self.pipe = _engine.StreamPipeline(self.per, self.H, self.W, depth=12, device=self.dev, mode=self.mode)
             stager = threading.Thread(target=stage, daemon=True)
             # (the pipeline thread needs the interpreter for a few calls per chunk; while the worker builds dicts it would
             # wait a whole switch interval - 5 ms by default - for each of them)
@@ -321,7 +391,10 @@ class _BatchRunner:
             sys.setswitchinterval(1e-4)
             try:
                 stager.start()
-                self.pipe.run(jobs(), on_done, r_2_threshold, radius, PY2_ROUND)
+                if n_lanes > 0:
+                    run_lanes()
+                else:
+                    self.pipe.run(jobs(), on_done, r_2_threshold, radius, PY2_ROUND)
             finally:
                 sys.setswitchinterval(interval)
                 while stager.is_alive():                    # (only after a failure: let it run out)

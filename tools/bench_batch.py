@@ -16,6 +16,8 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     size = int(sys.argv[2]) if len(sys.argv) > 2 else 512
     spots = int(sys.argv[3]) if len(sys.argv) > 3 else 500
+    if os.environ.get("DICT_SLICE"):
+        pflib.DICT_SLICE_PEAKS = int(os.environ["DICT_SLICE"])
     if len(sys.argv) > 4:
         pflib.CHUNK_PIXELS = int(sys.argv[4]) * size * size
         pflib.WINDOW_PIXELS = 8 * pflib.CHUNK_PIXELS
