@@ -118,6 +118,52 @@ def split_peak_records(rec, pixel_format=N.PIXELS_U16):
     return rows, fit, sub
 
 
+class PathRunner:
+    """fsq_find_peptides - the whole path (detect -> fit -> consolidate -> peak records) of a batch of same-shaped fields as ONE
+    library call on the current stream, with its own workspace: no interpreter between the stages (the calling thread holds
+    the interpreter lock only to make the call).  Buffers grow on demand (FSQ_ERANGE tells by how much)."""
+
+    def __init__(self, n_fields, H, W, device=None, cand_cap=None, record_cap=None):
+        torch = _torch()
+        self.torch = torch
+        self.dev = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
+        self.L = N.lib()
+        self.n_fields, self.H, self.W = int(n_fields), int(H), int(W)
+        self.offsets = torch.zeros(self.n_fields + 1, dtype=torch.int32, device=self.dev)
+        self.nkeep = torch.zeros(self.n_fields + 1, dtype=torch.int32, device=self.dev)
+        self._size(int(cand_cap or self.n_fields * max(1024, self.H * self.W // 48)), int(record_cap or self.n_fields * max(256, self.H * self.W // 400)))
+
+    def _size(self, cand_cap, record_cap):
+        torch = self.torch
+        self.cand_cap, self.record_cap = int(cand_cap), int(record_cap)
+        nbytes = self.L.fsq_find_peptides_workspace_bytes(self.n_fields, self.H, self.W, self.cand_cap, self.record_cap)
+        if nbytes < 0:
+            raise ValueError("invalid batch shape")
+        self.ws = None
+        self.records = None
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+        self.records = torch.empty((self.record_cap, PEAK_RECORD_BYTES), dtype=torch.uint8, device=self.dev)
+
+    def run(self, d_img, prm, r2_threshold=0.7, radius=4, mode=N.MODE_REF, py2_round=True):
+        """-> (records uint8[k, PEAK_RECORD_BYTES] - a view of this runner's buffer, valid until its next run -, offsets int32[n + 1],
+        nkeep int32[n + 1], candidates) on the device; enqueued on the current stream."""
+        ncand, nrec = ctypes.c_int64(0), ctypes.c_int64(0)
+        n_fields = int(d_img.shape[0])              # (any number of fields up to the capacity the runner was built for)
+        if not (1 <= n_fields <= self.n_fields) or tuple(d_img.shape[1:]) != (self.H, self.W):
+            raise ValueError("d_img must hold 1 .. %d fields of %d x %d" % (self.n_fields, self.H, self.W))
+        while True:
+            rc = self.L.fsq_find_peptides(d_img.data_ptr(), n_fields, self.H, self.W, ctypes.byref(prm), float(r2_threshold),
+                                          int(radius), 1 if py2_round else 0, int(mode), self.cand_cap, self.records.data_ptr(),
+                                          self.record_cap, self.offsets.data_ptr(), self.nkeep.data_ptr(), ctypes.byref(ncand),
+                                          ctypes.byref(nrec), self.ws.data_ptr(), self.ws.numel(),
+                                          self.torch.cuda.current_stream(self.dev).cuda_stream)
+            if rc != N.FSQ_ERANGE:
+                break
+            self._size(max(self.cand_cap, ncand.value + ncand.value // 8 + 1024), max(self.record_cap, nrec.value + nrec.value // 8 + 256))
+        N.check(rc, "fsq_find_peptides")
+        return self.records[:nrec.value], self.offsets[:n_fields + 1], self.nkeep[:n_fields + 1], ncand.value
+
+
 class DeviceBatch:
     """Results of one detect+fit+consolidate pass, still on the GPU."""
     __slots__ = ("n_fields", "H", "W", "cand", "counts", "offsets", "rows", "keep", "nkeep", "total", "thr")

@@ -216,6 +216,8 @@ def _run_cached_runner(key, factory, *args, **kw):
 
 #: stand-alone passes side by side when find_peptides_batch builds dicts (see _BatchRunner)
 DICT_LANES = 3
+#: ... whose first chunks are this many times smaller than the rest (one entry per group of DICT_LANES chunks)
+DICT_RAMP = "2"
 
 
 class _BatchRunner:
@@ -266,8 +268,25 @@ class _BatchRunner:
         torch, per = self.torch, self.per
         n_lanes = 0 if (raw or self.mode == N.MODE_TEXTBOOK_F32) else int(os.environ.get("FSQ_BATCH_LANES", DICT_LANES))
         n = len(words)
-        n_chunks = -(-n // per)
-        out = [None] * (n_chunks * per)
+        if n_lanes > 0:
+            # lanes take chunks of any size up to `per`: the first ones are small so that the first records - and with them the
+            # worker that builds the dicts, which is the longest chain of the call - start early
+            sizes, left = [], n
+            ramp = [int(x) for x in os.environ.get("FSQ_BATCH_RAMP", DICT_RAMP).split(",") if x]
+            for want in [max(1, per // dv) for dv in ramp for _ in range(n_lanes)]:
+                if left > per:
+                    sizes.append(min(want, left))
+                    left -= sizes[-1]
+            while left > 0:
+                sizes.append(min(per, left))
+                left -= sizes[-1]
+        else:
+            sizes = [min(per, n - c * per) for c in range(-(-n // per))]
+        first = [0]
+        for m in sizes:
+            first.append(first[-1] + m)
+        n_chunks = len(sizes)
+        out = [None] * (n if n_lanes > 0 else n_chunks * per)
         bufs = {}
         pool = concurrent.futures.ThreadPoolExecutor(1)
         futures = []
@@ -293,13 +312,15 @@ class _BatchRunner:
                                     raise item
                                 return
                             c, i = item
-                            d = self.pin[i].to(self.dev, non_blocking=True)
+                            d = self.pin[i][:sizes[c]].to(self.dev, non_blocking=True)
                             self.pin_ev[i] = torch.cuda.Event()
                             self.pin_ev[i].record()
                             self.pin_free[i].set()
-                            eng.run(d, prm, r_2_threshold, radius, self.mode, PY2_ROUND)
-                            rec, offs = eng.peak_records(d)
-                            nk = eng.nkeep[:per].clone()
+                            # the whole path of the chunk as one library call (no interpreter between the stages: the
+                            # worker that builds the dicts has it); the runner's buffers are re-used, so what the worker
+                            # will copy to the host is cloned
+                            rec, offs, nk, _ = eng.run(d, prm, r_2_threshold, radius, self.mode, PY2_ROUND)
+                            rec, offs, nk = rec.clone(), offs[:sizes[c] + 1].clone(), nk[:sizes[c]].clone()
                             ev = torch.cuda.Event()
                             ev.record()
                             futures.append(pool.submit(materialise, c, rec, offs, nk, ev))
@@ -318,7 +339,7 @@ class _BatchRunner:
         def stage():        # (own thread) copies the chunks into the pinned staging buffers ahead of the pipeline
             try:
                 for c in range(n_chunks):
-                    part = words[c * per:(c + 1) * per]
+                    part = words[first[c]:first[c + 1]]
                     i = c % 4
                     self.pin_free[i].wait()                 # (the consumer of the chunk last staged here has issued its upload ...)
                     self.pin_free[i].clear()
@@ -326,7 +347,7 @@ class _BatchRunner:
                         self.pin_ev[i].synchronize()        # (... and the upload is done)
                     host = self.pin[i].numpy().view(np.uint16)
                     host[:len(part)] = part
-                    if len(part) < per:                     # the last chunk is filled up with copies of its last field
+                    if len(part) < per and n_lanes == 0:    # (pipeline engines have a fixed field count: the last chunk is filled up with copies of its last field)
                         host[len(part):] = part[-1]
                     staged.put((c, i) if n_lanes > 0 else i)
                 if n_lanes > 0:
@@ -362,9 +383,12 @@ class _BatchRunner:
                 return
             failed = set(int(f) for f in np.nonzero(nk < 0)[0])
             dicts = _records_to_dicts(_engine.peak_record_view(self.rec_pin[:k].numpy()), None, None, offs, failed, fmt)
-            out[c * per:(c + 1) * per] = dicts
+            if n_lanes > 0:
+                out[first[c]:first[c + 1]] = dicts
+            else:
+                out[c * per:(c + 1) * per] = dicts
             if on_chunk is not None:
-                on_chunk(c * per, dicts[:max(0, min(per, n - c * per))])
+                on_chunk(first[c], dicts[:sizes[c]])
 
         def on_done(c, eng, total):                         # (side stream current, the chunk consolidated on it)
             rec, offs = eng.peak_records(bufs.pop(c))
@@ -380,7 +404,7 @@ class _BatchRunner:
             for e in self.pin_free:         # (a call that failed may have left a buffer marked busy)
                 e.set()
             if n_lanes > 0 and (self.lane_engines is None or len(self.lane_engines) != n_lanes):
-                self.lane_engines = [_engine.Engine(self.per, self.H, self.W, device=self.dev) for _ in range(n_lanes)]
+                self.lane_engines = [_engine.PathRunner(self.per, self.H, self.W, device=self.dev) for _ in range(n_lanes)]
                 self.lane_streams = [torch.cuda.Stream(device=self.dev) for _ in range(n_lanes)]
             if n_lanes == 0 and self.pipe is None:
                 self.pipe = _engine.StreamPipeline(self.per, self.H, self.W, depth=12, device=self.dev, mode=self.mode)

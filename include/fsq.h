@@ -184,6 +184,33 @@ int fsq_consolidate(FsqRow* d_rows, const int32_t* d_counts, const int32_t* d_of
 int fsq_kept_rows(const FsqRow* d_rows, const int32_t* d_keep, const int32_t* d_offsets, const int32_t* d_nkeep,
                   int n_fields, FsqRow* d_out, int64_t cap, int32_t* d_out_offsets, void* stream);
 
+/*
+ * THE WHOLE PATH IN ONE CALL: pflib.find_peptides (pflib.py:284-520) for every field of a batch already in HBM - candidate
+ * detection (:217-258), the LM fit of every candidate (:441-475), R^2 filter + consolidation + re-keying (:466, 477-519) -
+ * returning what the reference's dict holds per kept peak as a flat record table.  This is the entry point a binding of the
+ * reference's find_peptides(image) -> dict would use; it composes fsq_detect, fsq_fit_candidates,
+ * fsq_consolidate, fsq_kept_rows and fsq_fit_images on the caller's stream and workspace.
+ *   d_img              uint16 / binary16 [n_fields][H][W] (prm->pixel_format)
+ *   mode               FSQ_MODE_REF / FSQ_MODE_TEXTBOOK / FSQ_MODE_TEXTBOOK_F32
+ *   cand_cap           candidates the workspace is sized for (all fields together)
+ *   d_records          uint8[record_cap][FSQ_PEAK_RECORD_BYTES] out, fields in order, a field's peaks in the reference's dict
+ *                      order: bytes 0..127 the FsqRow, 128..327 fit_img double[25] (gaussfitter.py:253), 328..377 the 25
+ *                      16-bit pixel words of sub_img as they sit in d_img (pflib.py:443)
+ *   d_record_offsets   int32[n_fields + 1] out: field f's records are [offsets[f], offsets[f + 1])
+ *   d_nkeep            int32[n_fields + 1] out: kept peaks per field, -1 where the reference's assert (pflib.py:518) would
+ *                      fire (such a field has no records); [n_fields] = total
+ *   n_candidates, n_records   host out (may be NULL)
+ * Returns FSQ_ERANGE when cand_cap or record_cap is too small - *n_candidates / *n_records then hold what is needed and the
+ * call can be repeated with a larger workspace.  Synchronises the stream twice (the candidate total and the kept total size
+ * the following launches); the records themselves are complete when the work enqueued on `stream` is.
+ */
+#define FSQ_PEAK_RECORD_BYTES 378
+int64_t fsq_find_peptides_workspace_bytes(int n_fields, int H, int W, int64_t cand_cap, int64_t record_cap);
+int fsq_find_peptides(const void* d_img, int n_fields, int H, int W, const FsqDetectParams* prm, double r2_threshold,
+                      int radius, int py2_round, int mode, int64_t cand_cap, void* d_records, int64_t record_cap,
+                      int32_t* d_record_offsets, int32_t* d_nkeep, int64_t* n_candidates, int64_t* n_records,
+                      void* d_workspace, int64_t workspace_bytes, void* stream);
+
 /* fit_img (double[n][25]) of rows selected by d_idx[n] (NULL = all first n rows). */
 int fsq_fit_images(const FsqRow* d_rows, const int32_t* d_idx, int64_t n, double* d_fit_img, void* stream);
 

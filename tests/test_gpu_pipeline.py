@@ -152,3 +152,25 @@ def test_concurrent_calls_and_cache_eviction():
         t.join(timeout=600)
         assert not t.is_alive()
     assert not errs, errs[:3]
+
+
+def test_whole_path_entry_point_equals_the_staged_calls():
+    """fsq_find_peptides (one call: images in HBM -> peak records) gives byte for byte the records the Python layer assembles
+    from fsq_detect / fsq_fit_candidates / fsq_consolidate / fsq_kept_rows / fsq_fit_images, also when its buffers start too
+    small (FSQ_ERANGE -> grown) and for float16 pixels."""
+    import torch
+    from fluorosequencingimageanalysis_amd import _native as N, engine as E, pflib, synth
+    imgs = np.stack([synth.make_field(40 + i, (96, 128), 10 + 7 * i) for i in range(5)])
+    for stack in (imgs, imgs.astype(np.float16)):
+        words, fmt = E.as_pixel_fields(stack)
+        prm = E.detect_params(5, pflib.default_correlation_matrix, 2, fmt)
+        d = E.to_device_u16(words)
+        eng = E.Engine(5, 96, 128)
+        eng.run(d, prm, 0.7, 4, N.MODE_REF, True)
+        rec0, offs0 = eng.peak_records(d)
+        for caps in ((None, None), (64, 8)):
+            pr = E.PathRunner(5, 96, 128, cand_cap=caps[0], record_cap=caps[1])
+            rec, offs, nk, ncand = pr.run(d, prm, 0.7, 4, N.MODE_REF, True)
+            torch.cuda.synchronize()
+            assert ncand == int(eng.offsets[5].item()) and len(rec) == len(rec0) > 20
+            assert torch.equal(rec, rec0) and torch.equal(offs, offs0) and torch.equal(nk, eng.nkeep)
