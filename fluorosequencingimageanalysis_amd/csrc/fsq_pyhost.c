@@ -1,0 +1,151 @@
+/* fsq_pyhost.c - host-side CPython extension (_fsq_pyhost): the peak records of a batch -> the reference's per-field dicts.
+ *
+ * pflib.find_peptides returns {(h, w): (h_0, w_0, H, A, sigma_h, sigma_w, theta, sub_img, fit_img, rmse, r_2, s_n)} per image
+ * (pflib.py:396-407, 475, 514-520).  The GPU path delivers the kept peaks of a whole batch as flat 378-byte records
+ * (include/fsq.h, fsq_find_peptides); turning half a million of them into Python objects is what bounds
+ * pflib.find_peptides_batch.  This module does that conversion in C - same objects, same types as the Python
+ * builder it replaces (pflib._records_to_dicts_py): numpy.float64 scalars, a Python float for rmse (the reference's
+ * math.sqrt result), int64 / float64 5x5 arrays that are views of one block per field, plain int keys.
+ * Host logic only: no GPU code, no part of the numerical path.
+ */
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+#define NPY_NO_DEPRECATED_API NPY_1_7_API_VERSION
+#include <numpy/arrayobject.h>
+#include <numpy/arrayscalars.h>
+#include <stdint.h>
+#include <string.h>
+
+#define REC_BYTES 378
+/* byte offsets inside a record: the FsqRow of include/fsq.h, then fit_img double[25], then the 25 pixel words of sub_img */
+enum { O_H0 = 0, O_W0 = 8, O_HH = 16, O_A = 24, O_SH = 32, O_SW = 40, O_TH = 48, O_RMSE = 56, O_R2 = 64, O_SN = 72,
+       O_KEYH = 120, O_KEYW = 124, O_FIT = 128, O_SUB = 328 };
+
+static inline double rd_f64(const unsigned char* p) { double v; memcpy(&v, p, 8); return v; }
+static inline int32_t rd_i32(const unsigned char* p) { int32_t v; memcpy(&v, p, 4); return v; }
+
+/* the integer value of a pixel word: uint16 as it is, binary16 truncated toward zero (numpy's float16 -> int64) */
+static inline int64_t pixel_value(uint16_t w, int f16)
+{
+    if (!f16) return (int64_t)w;
+    const unsigned e = (w >> 10) & 31u, m = w & 1023u;
+    const unsigned v = 1024u | m;
+    int64_t r;
+    if (e == 31u) return 0;                     /* (inf / nan never pass the boundary, engine.as_pixel_fields) */
+    if (e < 15u) r = 0;
+    else r = e >= 25u ? ((int64_t)v << (e - 25u)) : (int64_t)(v >> (25u - e));
+    return (w & 0x8000u) ? -r : r;
+}
+
+static PyObject* f64_scalar(double v)
+{
+    PyObject* o = PyArrayScalar_New(Double);
+    if (o) PyArrayScalar_ASSIGN(o, Double, v);
+    return o;
+}
+
+/* a 5x5 view of row `i` of the C-contiguous block [m][5][5] (what iterating the block in Python yields) */
+static PyObject* view5x5(PyArrayObject* block, Py_ssize_t i)
+{
+    npy_intp dims[2] = {5, 5};
+    const npy_intp item = PyArray_ITEMSIZE(block);
+    npy_intp strides[2] = {5 * item, item};
+    PyArray_Descr* d = PyArray_DESCR(block);
+    Py_INCREF(d);
+    PyObject* v = PyArray_NewFromDescr(&PyArray_Type, d, 2, dims, strides, PyArray_BYTES(block) + i * 25 * item,
+                                       NPY_ARRAY_C_CONTIGUOUS | NPY_ARRAY_ALIGNED | NPY_ARRAY_WRITEABLE, NULL);
+    if (!v) return NULL;
+    Py_INCREF(block);
+    if (PyArray_SetBaseObject((PyArrayObject*)v, (PyObject*)block) < 0) { Py_DECREF(v); return NULL; }
+    return v;
+}
+
+/* one field: records [a, b) -> dict */
+static PyObject* field_dict(const unsigned char* rec, Py_ssize_t a, Py_ssize_t b, int f16)
+{
+    const Py_ssize_t m = b - a;
+    PyObject* d = PyDict_New();
+    if (!d || m == 0) return d;
+    npy_intp dims[3] = {m, 5, 5};
+    PyArrayObject* fit = (PyArrayObject*)PyArray_SimpleNew(3, dims, NPY_DOUBLE);
+    PyArrayObject* sub = (PyArrayObject*)PyArray_SimpleNew(3, dims, NPY_INT64);
+    if (!fit || !sub) goto fail;
+    {
+        double* pf = (double*)PyArray_DATA(fit);
+        int64_t* ps = (int64_t*)PyArray_DATA(sub);
+        for (Py_ssize_t i = 0; i < m; i++) {
+            const unsigned char* r = rec + (a + i) * REC_BYTES;
+            memcpy(pf + i * 25, r + O_FIT, 200);
+            for (int k = 0; k < 25; k++) { uint16_t w; memcpy(&w, r + O_SUB + 2 * k, 2); ps[i * 25 + k] = pixel_value(w, f16); }
+        }
+    }
+    for (Py_ssize_t i = 0; i < m; i++) {
+        const unsigned char* r = rec + (a + i) * REC_BYTES;
+        PyObject* t = PyTuple_New(12);
+        if (!t) goto fail;
+        static const int off7[7] = {O_H0, O_W0, O_HH, O_A, O_SH, O_SW, O_TH};
+        int ok = 1;
+        for (int k = 0; k < 7 && ok; k++) { PyObject* o = f64_scalar(rd_f64(r + off7[k])); if (!o) ok = 0; else PyTuple_SET_ITEM(t, k, o); }
+        if (ok) { PyObject* o = view5x5(sub, i); if (!o) ok = 0; else PyTuple_SET_ITEM(t, 7, o); }
+        if (ok) { PyObject* o = view5x5(fit, i); if (!o) ok = 0; else PyTuple_SET_ITEM(t, 8, o); }
+        if (ok) { PyObject* o = PyFloat_FromDouble(rd_f64(r + O_RMSE)); if (!o) ok = 0; else PyTuple_SET_ITEM(t, 9, o); }
+        if (ok) { PyObject* o = f64_scalar(rd_f64(r + O_R2)); if (!o) ok = 0; else PyTuple_SET_ITEM(t, 10, o); }
+        if (ok) { PyObject* o = f64_scalar(rd_f64(r + O_SN)); if (!o) ok = 0; else PyTuple_SET_ITEM(t, 11, o); }
+        PyObject* key = ok ? Py_BuildValue("(ii)", (int)rd_i32(r + O_KEYH), (int)rd_i32(r + O_KEYW)) : NULL;
+        if (!key || PyDict_SetItem(d, key, t) < 0) { Py_XDECREF(key); Py_DECREF(t); goto fail; }
+        Py_DECREF(key);
+        Py_DECREF(t);
+    }
+    Py_DECREF(fit);
+    Py_DECREF(sub);
+    return d;
+fail:
+    Py_XDECREF(fit);
+    Py_XDECREF(sub);
+    Py_DECREF(d);
+    return NULL;
+}
+
+/* fields_to_dicts(records, offsets, first_field, last_field, f16) -> list of dicts for fields first_field .. last_field - 1
+ *   records  a C-contiguous buffer of k x 378 bytes;  offsets  int64 buffer, offsets[f] .. offsets[f + 1] = field f's records */
+static PyObject* fields_to_dicts(PyObject* self, PyObject* args)
+{
+    Py_buffer rec, offs;
+    Py_ssize_t f0, f1;
+    int f16;
+    if (!PyArg_ParseTuple(args, "y*y*nnp", &rec, &offs, &f0, &f1, &f16)) return NULL;
+    PyObject* out = NULL;
+    const Py_ssize_t nrec = rec.len / REC_BYTES, noff = offs.len / 8;
+    const int64_t* o = (const int64_t*)offs.buf;
+    if (rec.len % REC_BYTES || offs.len % 8 || f0 < 0 || f1 < f0 || f1 + 1 > noff) {
+        PyErr_SetString(PyExc_ValueError, "fields_to_dicts: bad buffer sizes / field range");
+        goto done;
+    }
+    for (Py_ssize_t f = f0; f < f1; f++)
+        if (o[f] < 0 || o[f + 1] < o[f] || o[f + 1] > nrec) {
+            PyErr_SetString(PyExc_ValueError, "fields_to_dicts: offsets out of range");
+            goto done;
+        }
+    out = PyList_New(f1 - f0);
+    if (!out) goto done;
+    for (Py_ssize_t f = f0; f < f1; f++) {
+        PyObject* d = field_dict((const unsigned char*)rec.buf, (Py_ssize_t)o[f], (Py_ssize_t)o[f + 1], f16);
+        if (!d) { Py_CLEAR(out); goto done; }
+        PyList_SET_ITEM(out, f - f0, d);
+    }
+done:
+    PyBuffer_Release(&rec);
+    PyBuffer_Release(&offs);
+    return out;
+}
+
+static PyMethodDef methods[] = {
+    {"fields_to_dicts", fields_to_dicts, METH_VARARGS, "peak records of fields [first, last) -> list of {(h, w): 12-tuple} dicts"},
+    {NULL, NULL, 0, NULL}};
+static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_fsq_pyhost", "host-side helpers of fluorosequencingimageanalysis_amd", -1, methods};
+
+PyMODINIT_FUNC PyInit__fsq_pyhost(void)
+{
+    import_array();
+    return PyModule_Create(&moddef);
+}

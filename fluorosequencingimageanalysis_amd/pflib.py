@@ -137,7 +137,42 @@ def illumina_s_n(sub_img):
 DICT_SLICE_PEAKS = 2048
 
 
+try:                                    # host-side C extension (csrc/fsq_pyhost.c, built by the Makefile): the same objects, twice as fast
+    from . import _fsq_pyhost
+except ImportError:                     # (not built: the interpreter does the same work)
+    _fsq_pyhost = None
+
+
 def _records_to_dicts(rows, fit, sub, offs, failed=(), pixel_format=N.PIXELS_U16):
+    """Peak records of a batch -> one {(h, w): 12-tuple} per field (AssertionError instances for the fields in `failed`).
+    With the records themselves (fit and sub None, engine.peak_record_view) the C builder does it, a few fields per call so
+    that other threads get the interpreter in between; _records_to_dicts_py is the same in Python (and what the C builder
+    is tested against)."""
+    if fit is not None or _fsq_pyhost is None or rows.dtype != _engine.RECORD_DTYPE or not rows.flags.c_contiguous:
+        return _records_to_dicts_py(rows, fit, sub, offs, failed, pixel_format)
+    was_enabled = gc.isenabled()
+    gc.disable()                        # (millions of fresh containers, none of them cyclic)
+    try:
+        raw = rows.view(np.uint8).reshape(-1, _engine.PEAK_RECORD_BYTES)
+        o = np.ascontiguousarray(offs, dtype=np.int64)
+        n_fields = len(o) - 1
+        out = []
+        f0 = 0
+        while f0 < n_fields:
+            f1 = f0 + 1
+            while f1 < n_fields and o[f1 + 1] - o[f0] <= DICT_SLICE_PEAKS:
+                f1 += 1
+            out.extend(_fsq_pyhost.fields_to_dicts(raw, o, f0, f1, pixel_format == N.PIXELS_F16))
+            f0 = f1
+        for f in failed:
+            out[f] = AssertionError("field %d: re-keyed peak collides with an existing key (pflib.py:518)" % f)
+        return out
+    finally:
+        if was_enabled:
+            gc.enable()
+
+
+def _records_to_dicts_py(rows, fit, sub, offs, failed=(), pixel_format=N.PIXELS_U16):
     """Peak records of a batch -> one {(h, w): 12-tuple} per field, in the reference's
     dict order (pflib.py:396-407, 475, 514-519); fields listed in `failed` give an AssertionError instance instead.
     Built column-wise: the value types are the reference's (numpy.float64 scalars, a Python float for rmse, 5x5 arrays -
@@ -320,10 +355,19 @@ class _BatchRunner:
                             # worker that builds the dicts has it); the runner's buffers are re-used, so what the worker
                             # will copy to the host is cloned
                             rec, offs, nk, _ = eng.run(d, prm, r_2_threshold, radius, self.mode, PY2_ROUND)
-                            rec, offs, nk = rec.clone(), offs[:sizes[c] + 1].clone(), nk[:sizes[c]].clone()
+                            # records and counts go to pinned host buffers on this lane's stream right away (the runner's
+                            # device buffers are free for its next chunk, stream order); the worker only waits for the event
+                            m, kk = sizes[c], int(rec.shape[0])
+                            j = self.land_free.get()
+                            if self.land_rec[j] is None or self.land_rec[j].shape[0] < kk:
+                                self.land_rec[j] = torch.empty((kk + kk // 4 + 1024, _engine.PEAK_RECORD_BYTES), dtype=torch.uint8).pin_memory()
+                            if self.land_meta[j] is None or self.land_meta[j].shape[0] < 2 * per + 2:
+                                self.land_meta[j] = torch.empty(2 * per + 2, dtype=torch.int32).pin_memory()
+                            self.land_rec[j][:kk].copy_(rec, non_blocking=True)
+                            self.land_meta[j][:2 * m + 1].copy_(torch.cat([nk[:m], offs[:m + 1]]), non_blocking=True)
                             ev = torch.cuda.Event()
                             ev.record()
-                            futures.append(pool.submit(materialise, c, rec, offs, nk, ev))
+                            futures.append(pool.submit(materialise_landed, c, j, kk, m, ev))
                         self.lane_streams[k].synchronize()
                 except BaseException as e:      # noqa: BLE001 - re-raised by the caller
                     errs.append(e)
@@ -390,6 +434,19 @@ class _BatchRunner:
             if on_chunk is not None:
                 on_chunk(first[c], dicts[:sizes[c]])
 
+        def materialise_landed(c, j, kk, m, ev):            # (lanes: the chunk's records are already on their way to land_rec[j])
+            try:
+                ev.synchronize()
+                meta = self.land_meta[j][:2 * m + 1].numpy()
+                nk, offs = meta[:m].copy(), meta[m:].copy()
+                failed = set(int(f) for f in np.nonzero(nk < 0)[0])
+                dicts = _records_to_dicts(_engine.peak_record_view(self.land_rec[j][:kk].numpy()), None, None, offs, failed, fmt)
+            finally:
+                self.land_free.put(j)
+            out[first[c]:first[c + 1]] = dicts
+            if on_chunk is not None:
+                on_chunk(first[c], dicts[:sizes[c]])
+
         def on_done(c, eng, total):                         # (side stream current, the chunk consolidated on it)
             rec, offs = eng.peak_records(bufs.pop(c))
             nk = eng.nkeep[:per].clone()
@@ -403,9 +460,14 @@ class _BatchRunner:
                 raise _RunnerClosed()
             for e in self.pin_free:         # (a call that failed may have left a buffer marked busy)
                 e.set()
+            self.land_free = _queue.Queue()
+            for j in range(n_lanes + 2):
+                self.land_free.put(j)
             if n_lanes > 0 and (self.lane_engines is None or len(self.lane_engines) != n_lanes):
                 self.lane_engines = [_engine.PathRunner(self.per, self.H, self.W, device=self.dev) for _ in range(n_lanes)]
                 self.lane_streams = [torch.cuda.Stream(device=self.dev) for _ in range(n_lanes)]
+                self.land_rec = [None] * (n_lanes + 2)      # pinned landing buffers of the chunks' records / counts
+                self.land_meta = [None] * (n_lanes + 2)
             if n_lanes == 0 and self.pipe is None:
                 self.pipe = _engine.StreamPipeline(self.per, self.H, self.W, depth=12, device=self.dev, mode=self.mode)
             stager = threading.Thread(target=stage, daemon=True)

@@ -102,3 +102,42 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "fsq_oracle" not in src and "libfsq_oracle" not in src, f
+
+
+def test_c_dict_builder_equals_python_builder():
+    """csrc/fsq_pyhost.c (peak records -> the reference's dicts) against the Python builder on synthetic records: keys, order,
+    value types (numpy.float64 scalars, a Python float for rmse, int64 / float64 5x5 views of one block per field), NaN metrics,
+    empty fields, failed fields, float16 pixel words."""
+    from fluorosequencingimageanalysis_amd import _native as N, engine as E, pflib
+    assert pflib._fsq_pyhost is not None, "the host extension was not built (make -C fluorosequencingimageanalysis_amd/csrc)"
+    rng = np.random.default_rng(5)
+    n = 5000
+    for fmt in (N.PIXELS_U16, N.PIXELS_F16):
+        rec = rng.integers(0, 255, (n, E.PEAK_RECORD_BYTES), dtype=np.uint8)
+        v = E.peak_record_view(rec)
+        v["key_h"] = rng.integers(0, 512, n)
+        v["key_w"] = np.arange(n)
+        for k in ("h0", "w0", "H", "A", "sigma_h", "sigma_w", "theta", "rmse", "r2", "s_n"):
+            v[k] = rng.normal(0, 100, n)
+        v["r2"][::7] = np.nan
+        v["fit"] = rng.normal(0, 1, (n, 5, 5))
+        v["sub"] = rng.integers(0, 0x7c00 if fmt == N.PIXELS_F16 else 65536, (n, 5, 5))
+        counts = rng.multinomial(n, np.ones(40) / 40)
+        counts[3] = 0
+        offs = np.concatenate([[0], np.cumsum(counts)])
+        failed = {5, 39}
+        a = pflib._records_to_dicts(v, None, None, offs, failed, fmt)
+        b = pflib._records_to_dicts_py(v, None, None, offs, failed, fmt)
+        assert len(a) == len(b) == 40 and a[3] == {} and isinstance(a[5], AssertionError) and isinstance(a[39], AssertionError)
+        assert str(a[5]) == str(b[5])
+        for x, y in zip(a, b):
+            if isinstance(x, AssertionError):
+                continue
+            assert list(x) == list(y) and all(type(k[0]) is int and type(k[1]) is int for k in x)
+            for p, q in zip(x.values(), y.values()):
+                assert type(p) is tuple and len(p) == 12
+                for i in (0, 1, 2, 3, 4, 5, 6, 9, 10, 11):
+                    assert type(p[i]) is type(q[i]) and (p[i] == q[i] or (p[i] != p[i] and q[i] != q[i]))
+                for i in (7, 8):
+                    assert p[i].dtype == q[i].dtype and p[i].shape == (5, 5) and p[i].flags.writeable and p[i].flags.c_contiguous
+                    assert not p[i].flags.owndata and p[i].base is not None and np.array_equal(p[i], q[i])
