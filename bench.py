@@ -428,7 +428,7 @@ def extras(a, torch, E, N, pflib, imgs, d_img, prm, dev):
     # the drop-in surface: host stack in, list of dicts of 12-tuples out (H2D, streamed chunks, D2H, Python objects)
     pflib.find_peptides_batch(imgs[:256])
     best = None
-    for _ in range(2):
+    for _ in range(3):
         t0 = time.perf_counter()
         d = pflib.find_peptides_batch(imgs)
         dt = time.perf_counter() - t0
@@ -439,10 +439,15 @@ def extras(a, torch, E, N, pflib, imgs, d_img, prm, dev):
     out["find_peptides_batch_note"] = ("pflib.find_peptides_batch on %d host fields -> list of dicts of 12-tuples (pinned H2D, chunks "
                                        "of %d fields fitted by stand-alone passes in 3 lanes, D2H, dicts built by a worker thread "
                                        "while the next chunks are fitted; %d peaks)" % (len(imgs), pflib.CHUNK_PIXELS // (a.size * a.size), npk))
-    t0 = time.perf_counter()
-    rec, counts, _fmt = pflib.find_peptides_records(imgs)
-    dt = time.perf_counter() - t0
-    out["find_peptides_records_fields_per_sec"] = len(imgs) / dt
+    pflib.find_peptides_records(imgs[:256])                 # (builds this path's pipeline, as the 256-field call above did for the lanes)
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        rec, counts, _fmt = pflib.find_peptides_records(imgs)
+        dt = time.perf_counter() - t0
+        del rec
+        best = dt if best is None else min(best, dt)
+    out["find_peptides_records_fields_per_sec"] = len(imgs) / best
     out["find_peptides_records_note"] = "the same stack through the continuous-batching pipeline, returned as byte tables (no Python objects per peak)"
     # the command line end to end: a directory of 16-bit TIFFs -> pickle + CSV per image
     m = min(256, len(imgs))
