@@ -3,6 +3,7 @@
  * image hot path.  The reference (marcottelab/FluorosequencingImageAnalysis) is pure Python and has
  * no FFI; these entry points are what a binding for that path binds instead of the Python bodies:
  *
+ *   fsq_find_peptides      <- pflib.find_peptides as a whole   pflib.py:284-520 (composes the four below; one call per batch)
  *   fsq_detect             <- pflib._psf_candidates            pflib.py:217-258
  *   fsq_fit_candidates     <- the candidate loop of pflib.find_peptides (pflib.py:441-477):
  *                             pflib._fit_2d_gaussian :180-214 -> gaussfitter.gaussfit
@@ -11,6 +12,10 @@
  *   fsq_consolidate        <- R^2 filter + consolidation + re-key   pflib.py:466, 479-519
  *   fsq_fit_images         <- gaussfitter.twodgaussian on the kept peaks  gaussfitter.py:253
  *   fsq_phase_correlate    <- phase_correlate.phase_correlate  phase_correlate.py:11-134
+ *   fsq_fitq_*             <- the image loop around the fits    pflib.py:940-996, 1082-1099 (continuous batching)
+ *   fsq_greedy_tracking    <- Experiment.greedy_particle_tracking (+ accumulate_offsets / discard_dropouts)  flexlibrary.py:567-1027
+ *   fsq_centroid_tracking  <- Experiment.luminosity_centroid_particle_tracking  flexlibrary.py:1173-1317
+ *   fsq_mexican_hat        <- Spot.mexican_hat_photometry_metric  flexlibrary.py:172-210
  *
  * Conventions: every function returns 0 on success or a negative FSQ_E* code; nothing throws or
  * aborts.  All pointers named d_* are DEVICE pointers (HBM); the caller owns every buffer.  `stream`
