@@ -769,11 +769,70 @@ def read_image(image_path):
         return converted_path, np.array(im)
 
 
-def save_psfs_png(psfs, image_path=None, timestamp_epoch=None, output_path=None, **kwargs):
-    """The reference draws the fitted spots over a contrast-stretched copy of the image (pflib.py:749-880).  That
-    overlay is cosmetic and outside the hot path; nothing is written and None is returned, which is
-    what image_batch's result tuple then carries in its png slot."""
-    return None
+def _rescale_to_uint8(image):
+    """skimage.exposure.rescale_intensity(image, out_range=np.uint8) as the reference's scikit-image computes it
+    (exposure.py of 0.11-0.12: clip to the image's own [min, max], (image - min) / float(max - min) * 255, cast back to the
+    INPUT dtype) followed by the reference's .astype(np.uint8): both casts truncate.  A constant image (max == min) divides by
+    zero there (nan / a warning); here it gives zeros.  scikit-image is not installed in the build container: parity unpinned."""
+    img = np.asarray(image)
+    imin, imax = img.min(), img.max()
+    if imax == imin:
+        return np.zeros(img.shape, np.uint8)
+    scaled = (np.clip(img, imin, imax) - imin) / float(imax - imin) * 255.0
+    if np.issubdtype(img.dtype, np.integer):
+        scaled = scaled.astype(img.dtype)
+    return scaled.astype(np.uint8)
+
+
+def _intensity_scaling(image, **kwargs):
+    """contrast_filter of save_psfs_png (reference pflib.py:767-780): the image stretched linearly into 8 bits."""
+    return _rescale_to_uint8(image)
+
+
+def _histogram_equalization(image, **kwargs):
+    """contrast_filter of save_psfs_png (reference pflib.py:749-764): skimage.exposure.equalize_hist (for integer images: one
+    histogram bin per value between min and max, the cumulative distribution interpolated at every pixel) then stretched into
+    8 bits.  scikit-image is not installed in the build container: parity unpinned."""
+    img = np.asarray(image)
+    if np.issubdtype(img.dtype, np.integer):
+        lo = int(img.min())
+        hist = np.bincount((img.ravel().astype(np.int64) - lo))
+        centers = np.arange(lo, lo + len(hist))
+    else:
+        hist, edges = np.histogram(img.ravel(), bins=256)
+        centers = (edges[:-1] + edges[1:]) / 2.0
+    cdf = hist.cumsum() / float(hist.sum())
+    return _rescale_to_uint8(np.interp(img.ravel(), centers, cdf).reshape(img.shape))
+
+
+def save_psfs_png(psfs, image_path, timestamp_epoch=None, output_path=None, square_size=9, square_color='lightblue',
+                  square_colors=None, contrast_filter=_intensity_scaling, contrast_filter_args=None):
+    """Highlight the found PSFs with squares on a contrast-stretched 8-bit copy of the image and save it as a PNG; returns the
+    path.  Reference pflib.py:783-880: same arguments, same file name (_psfs_filename(image_path, epoch, '.png') unless
+    output_path is given), same drawing calls (PIL ImageOps.colorize of the 'L' image, one ImageDraw.rectangle outline per
+    peak, vertices (w -/+ radius, h -/+ radius) with radius = (square_size - 1) / 2 in Python-2 integer division), ValueError for
+    an even or too small square_size.  Host side only (PIL); the bytes of the PNG depend on the installed PIL / zlib and are
+    not pinned against the reference."""
+    from PIL import Image, ImageDraw, ImageOps
+    image_path = os.path.abspath(image_path)
+    if output_path is None:
+        if timestamp_epoch is None:
+            timestamp_epoch = _py2_round(time.time())
+        output_path = _psfs_filename(image_path, timestamp_epoch, '.png')
+    converted_path, image = read_image(image_path)
+    filtered_image = contrast_filter(image, **(contrast_filter_args or {}))
+    pillow_image = Image.fromarray(np.ascontiguousarray(filtered_image, dtype=np.uint8)).convert("L")
+    highlighted_image = ImageOps.colorize(pillow_image, (0, 0, 0), (255, 255, 255))
+    if square_size % 2 == 0 or square_size < 3:
+        raise ValueError("square_size must be an odd integer >= 3")
+    radius = (square_size - 1) // 2
+    draw = ImageDraw.Draw(highlighted_image)
+    for (h, w) in psfs.keys():
+        square = ((w - radius, h - radius), (w + radius, h + radius))
+        color = square_color if (square_colors is None or (h, w) not in square_colors) else square_colors[(h, w)]
+        draw.rectangle(square, fill=None, outline=color)
+    highlighted_image.save(output_path)
+    return output_path
 
 
 #: image_batch / _candidate_counts hold at most about this many pixels of one image shape in host memory before they are

@@ -141,12 +141,29 @@ def test_image_batch_semantics(tmp_path, fake_gpu, monkeypatch, caplog):
                                 find_peptides_parameters={"c_std": 3}, timestamp_epoch=1450000000.4)
     assert sorted(res) == [str(d / "a.tif"), str(d / "b.tif"), str(d / "c.tif")]
     conv, pkl, tab, png = res[str(d / "b.tif")]
-    assert conv == str(d / "b.tif.png") and pkl == conv + "_psfs_nzaj5s.pkl" and tab == conv + "_psfs_nzaj5s.csv" and png is None
+    assert conv == str(d / "b.tif.png") and pkl == conv + "_psfs_nzaj5s.pkl" and tab == conv + "_psfs_nzaj5s.csv" and png == conv + "_psfs_nzaj5s.png"
     assert res[str(d / "a.tif")][0] == str(d / "a.tif.png")                      # converted on the way, like the reference
     assert res[str(d / "a.tif")][1] == str(d / "a.tif.png") + "_psfs_nzaj5s.pkl"
     for v in res.values():
-        assert os.path.exists(v[1]) and os.path.exists(v[2])
+        assert os.path.exists(v[1]) and os.path.exists(v[2]) and os.path.exists(v[3])
         assert open(v[2]).read().splitlines()[1].split("\t")[0] == v[0]          # 'Absolute image path' = converted path
+    # the overlay (pflib.py:783-880): the image stretched into 8 bits, a light-blue 9 x 9 outline around every peak
+    import pickle
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        peaks = pickle.load(open(pkl, "rb"))
+    over = np.array(Image.open(png))
+    grey = pflib._intensity_scaling(img)
+    assert over.shape == img.shape + (3,) and len(peaks) > 3
+    outline = np.zeros(img.shape, bool)
+    for (h, w) in peaks:
+        for hh, ww in [(h - 4, x) for x in range(w - 4, w + 5)] + [(h + 4, x) for x in range(w - 4, w + 5)] + \
+                      [(y, w - 4) for y in range(h - 4, h + 5)] + [(y, w + 4) for y in range(h - 4, h + 5)]:
+            if 0 <= hh < img.shape[0] and 0 <= ww < img.shape[1]:
+                outline[hh, ww] = True
+    assert (over[outline] == (173, 216, 230)).all()
+    assert (over[~outline] == grey[~outline][:, None]).all()
     shapes = sorted(c[0] for c in fake_gpu)
     assert shapes == [(1, 64, 80), (3, 96, 96)] and all(c[1] == {"c_std": 3} for c in fake_gpu)
     # corrupt and missing: logged by convert_image and again by image_batch (as in the reference); re-key: once

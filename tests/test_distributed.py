@@ -182,8 +182,8 @@ def test_parallel_image_batch_world2(tmp_path):
     assert list(res) == good                                    # original paths, list order, the corrupt file missing
     for p in good:
         conv, pkl, tab, png = res[p]
-        assert conv == p + ".png" and pkl == conv + "_psfs_nzaj5s.pkl" and tab == conv + "_psfs_nzaj5s.csv" and png is None
-        assert os.path.exists(pkl) and os.path.exists(tab)
+        assert conv == p + ".png" and pkl == conv + "_psfs_nzaj5s.pkl" and tab == conv + "_psfs_nzaj5s.csv" and png == conv + "_psfs_nzaj5s.png"
+        assert os.path.exists(pkl) and os.path.exists(tab) and os.path.exists(png)
     # the assignment the ranks used: LPT over the counts (top-left pixels), balanced within the largest weight
     counts = [None if "corrupt" in p else int(os.path.basename(p)[2]) for p in paths]
     weights = {p: (50, 5, 90, 20, 35, 60, 10, 75)[int(os.path.basename(p)[2])] for p in good}

@@ -145,3 +145,31 @@ def test_c_dict_builder_equals_python_builder():
                 for i in (7, 8):
                     assert p[i].dtype == q[i].dtype and p[i].shape == (5, 5) and p[i].flags.writeable and p[i].flags.c_contiguous
                     assert not p[i].flags.owndata and p[i].base is not None and np.array_equal(p[i], q[i])
+
+
+def test_contrast_filters_and_overlay_arguments(tmp_path):
+    """pflib._intensity_scaling / _histogram_equalization / save_psfs_png (reference pflib.py:749-880; scikit-image is absent
+    here, so these follow its published arithmetic - parity unpinned): 8-bit results, truncating casts, monotone equalisation,
+    per-peak colours, the file name rule and the square_size check."""
+    from PIL import Image
+    from fluorosequencingimageanalysis_amd import pflib
+    img = (np.arange(64 * 48).reshape(64, 48) * 13 % 5000 + 100).astype(np.uint16)
+    s = pflib._intensity_scaling(img)
+    assert s.dtype == np.uint8 and s.min() == 0 and s.max() == 255
+    assert np.array_equal(s, ((img.astype(np.float64) - img.min()) / float(img.max() - img.min()) * 255.0).astype(np.uint16).astype(np.uint8))
+    assert (pflib._intensity_scaling(np.full((4, 4), 7, np.uint16)) == 0).all()
+    e = pflib._histogram_equalization(img)
+    assert e.dtype == np.uint8 and e.max() == 255
+    order = np.argsort(img.ravel(), kind="stable")
+    assert (np.diff(e.ravel()[order].astype(int)) >= 0).all()                      # monotone in the pixel value
+    p = str(tmp_path / "x.png")
+    Image.fromarray(img).save(p)
+    psfs = {(10, 12): None, (30, 20): None}
+    out = pflib.save_psfs_png(psfs, p, timestamp_epoch=1450000000.4, square_size=5, square_color="red",
+                              square_colors={(30, 20): "lime"}, contrast_filter=pflib._histogram_equalization)
+    assert out == p + "_psfs_nzaj5s.png"
+    over = np.array(Image.open(out))
+    assert tuple(over[8, 10]) == (255, 0, 0) and tuple(over[32, 22]) == (0, 255, 0) and tuple(over[10, 12]) == (e[10, 12],) * 3
+    assert pflib.save_psfs_png({}, p, output_path=str(tmp_path / "y.png")) == str(tmp_path / "y.png")
+    with pytest.raises(ValueError):
+        pflib.save_psfs_png(psfs, p, square_size=4)
