@@ -87,6 +87,20 @@ def _psf_candidates(image, median_filter_size=5, correlation_matrix=default_corr
     return [(int(h), int(w)) for _, h, w in cand]
 
 
+def _2d_gaussian_function(H, A, h_0, w_0, sigma_h, sigma_w, theta, h, w):
+    """The circular Gaussian the reference's Monte-Carlo fitter evaluates (pflib.py:93-114: sigma_w and theta are accepted and
+    not used there either): A * exp(-((h - h_0)^2 + (w - w_0)^2) / (2 sigma_h^2)) + H.  Host-side NumPy, as in the reference."""
+    a = (h - h_0) ** 2
+    b = (w - w_0) ** 2
+    return A * np.exp(-np.divide(a + b, 2 * sigma_h ** 2)) + H
+
+
+def _fit_2d_gaussian_monte_carlo(subimage, N_iter=10**3):
+    """pflib.py:117-177 draws N_iter parameter sets from numpy's global, unseeded random state and keeps the best: its output
+    differs from run to run in the reference itself, so there is nothing to reproduce."""
+    raise NotImplementedError("fit_type='monte_carlo' draws from an unseeded RNG in the reference (pflib.py:117-177) and is not reproduced")
+
+
 def _fit_2d_gaussian(subimage, implementation='agpy'):
     """Fit a 2D Gaussian to a 5x5 pixel area -> (h_0, w_0, H, A, sigma_h, sigma_w, theta, fit_img).
     Reference pflib.py:180-214 (h_0/w_0 in the 5x5 frame, as the reference returns them)."""
