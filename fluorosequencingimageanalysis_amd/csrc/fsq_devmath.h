@@ -233,6 +233,18 @@ FSQ_DEV double fsq_taylor_sin(double xx, double x, double dx)
     return x + t;
 }
 
+// Index into the sin / cos table (440 doubles, 4 per entry) from the low word of big + |x|.  For every argument of the
+// documented range the value is 0 .. 436 as it stands; the clamp is for lanes that run the function on GARBAGE - the step
+// round executes its trial evaluation on the lanes of a tile whose queue slots are dead (reserved by the Jacobian round and not
+// needed: only their tag is ever written), with whatever bits the workspace memory held; an unclamped index then read up to
+// 32 GB past the table (a GPU memory fault, found by round 3's fuzz once the workspace was recycled memory instead of fresh
+// zero pages).
+FSQ_DEV int fsq_sincos_index(double u)
+{
+    const unsigned k = (unsigned)fsq_bits(u) * 4u;
+    return (int)(k < 436u ? k : 436u);
+}
+
 FSQ_DEV double fsq_do_cos(double x, double dx)
 {
     if (x < 0) dx = -dx;
@@ -242,7 +254,7 @@ FSQ_DEV double fsq_do_cos(double x, double dx)
     double xx = x * x;
     double s = fsq_fma(x * xx, fsq_fma(SC_SN5, xx, SC_SN3), x);
     double c = xx * fsq_sc_polyc(xx);
-    int k = (int)(unsigned)fsq_bits(u) * 4;
+    const int k = fsq_sincos_index(u);
     double sn = FSQ_SINCOS_TAB[k], ssn = FSQ_SINCOS_TAB[k + 1], cs = FSQ_SINCOS_TAB[k + 2], ccs = FSQ_SINCOS_TAB[k + 3];
     double cor = fsq_fma(-s, ssn, ccs);
     cor = fsq_fma(-c, cs, cor);
@@ -261,7 +273,7 @@ FSQ_DEV double fsq_do_sin(double x, double dx)
     double xx = x * x;
     double s = x + fsq_fma(x * xx, fsq_fma(SC_SN5, xx, SC_SN3), dx);
     double c = fsq_fma(x, dx, xx * fsq_sc_polyc(xx));
-    int k = (int)(unsigned)fsq_bits(u) * 4;
+    const int k = fsq_sincos_index(u);
     double sn = FSQ_SINCOS_TAB[k], ssn = FSQ_SINCOS_TAB[k + 1], cs = FSQ_SINCOS_TAB[k + 2], ccs = FSQ_SINCOS_TAB[k + 3];
     double cor = fsq_fma(s, ccs, ssn);
     cor = fsq_fma(-c, sn, cor);

@@ -88,6 +88,8 @@ struct Ctx {
     FitOut* out;              // [pool]
     FitStat* stat;            // [pool]
     long long cap;            // queue capacity (positions)
+    long long pool;           // by-candidate slots
+    int* err;                 // first invariant a kernel found broken (0: none) - see fsq_guard
     int* slow_total;          // statistics: fits that went through the plain-division kernel
     int* done;                // [FSQ_MAX_TICKETS]: terminated fits per batch in flight
     int tshift;               // a record's tag = slot | ticket << tshift (one 32-bit word: the kernels are at the register limit)
@@ -95,6 +97,19 @@ struct Ctx {
     int force_redo;           // debug: take qrfac's norm re-computation branch at every step (FSQ_DEBUG_FORCE_NORM_RECOMPUTE)
     int force_slow_mod;       // debug: route every fit with idx % mod == 0 through the plain-division kernel
 };
+
+// Every queue position / pool slot a kernel is about to WRITE to is checked against the capacity first: the host sizes the
+// queues from upper bounds it keeps itself (FsqFitQueue::alive), and if one of those bounds were ever wrong the write would
+// land outside the workspace - a memory fault at best, silent damage at worst.  A position out of range is recorded (the
+// largest code wins; FsqFitQueue::look turns it into FSQ_EINTERNAL) and replaced by position 0, which is inside.
+enum { G_KINIT_POS = 1, G_KINIT_SLOT = 2, G_KA_BLO = 3, G_KA_BHI = 4, G_KA_OVERLAP = 5, G_KA_SLOW = 6, G_KB_C1 = 7, G_KB_C3 = 8, G_KB_A = 9,
+       G_KB_BLO = 10, G_KB_BHI = 11 };
+FSQ_DEV long long fsq_guard(const Ctx& c, long long v, long long limit, int code)
+{
+    if ((unsigned long long)v < (unsigned long long)limit) return v;
+    atomicMax(c.err, code);
+    return 0;
+}
 
 // Reserve one queue slot for every lane with `want` set: one atomic per wave (a single counter saturates at
 // ~90 atomics/us chip-wide, far below the millions of appends per round), slots in lane order.
@@ -201,9 +216,9 @@ __global__ void __launch_bounds__(256) kinit(Ctx c, BatchArgs b, double* __restr
     const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool ok = i0 < b.n;
     const long long i = ok ? i0 : 0;            // idle lanes of the last block recompute fit 0 and store nothing
-    const int pos = wave_reserve(cntA, ok && !b.no_queue);     // appended behind whatever the queue already holds
+    const long long pos = fsq_guard(c, wave_reserve(cntA, ok && !b.no_queue), c.cap, G_KINIT_POS);     // appended behind whatever the queue already holds
     if (b.n <= 0) return;
-    const long long slot = b.base + i;
+    const long long slot = fsq_guard(c, b.base + i, c.pool, G_KINIT_SLOT);
     double v[FSQ_NPIX];
     roi_pixels(b, i, v);
     if (ok) {
@@ -373,7 +388,14 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
         const bool b_hi = hist > 1;
         const int at_lo = wave_reserve(cnt_cur + CNT_BLO, active && cl == 0 && !b_hi);
         const int at_hi = wave_reserve(cnt_cur + CNT_BHI, active && cl == 0 && b_hi);
-        const long long at = __shfl(b_hi ? (int)(cap - 1) - at_hi : at_lo, gbase);
+        if (active && cl == 0) {      // (two lists in one array, growing towards each other)
+            if (!b_hi) fsq_guard(c, at_lo, cap, G_KA_BLO); else fsq_guard(c, at_hi, cap, G_KA_BHI);
+            if ((long long)at_lo + (long long)at_hi + 2 > cap && (at_lo > 0 || at_hi > 0)) {
+                const int nlo = b_hi ? cnt_cur[CNT_BLO] : at_lo + 1, nhi = b_hi ? at_hi + 1 : cnt_cur[CNT_BHI];
+                if ((long long)nlo + nhi > cap) atomicMax(c.err, (int)G_KA_OVERLAP);
+            }
+        }
+        const long long at = __shfl((int)fsq_guard(c, b_hi ? (long long)(cap - 1) - at_hi : (long long)at_lo, cap, b_hi ? G_KA_BHI : G_KA_BLO), gbase);
         const int idx = tag_slot(c, tag);
         const bool fresh = active && (nfev == 0);
         double llim1 = 0., fnorm = 0., xnorm = 0., delta = 0., par_in = 0.;
@@ -852,7 +874,7 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
         {
             bool go = active && (status == 0);
             if (FAST) {
-                int sat = wave_reserve(slow_cnt, qhz && cl == 0);
+                int sat = (int)fsq_guard(c, wave_reserve(slow_cnt, qhz && cl == 0), cap, G_KA_SLOW);
                 sat = __shfl(sat, gbase);
                 if (qhz) for (int f = cl; f < A_LEN; f += L) nt_st(SQ + (size_t)sat + f * cap, qa[f * cap]);
                 go = go && !qhz;
@@ -1030,8 +1052,8 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
                 // unfinished: park the fit (R / sdiag / par state as they stand) for the next round's launch
                 const bool park = live && !st.done;
                 const bool to_c1 = (st.iter < lims.lim[2]);            // (C 1 tiles run to lim[2], C 3 tiles to the end: always progress)
-                const int at1 = wave_reserve(cnt_next + CNT_C1, park && to_c1);
-                const int at3 = wave_reserve(cnt_next + CNT_C3, park && !to_c1);
+                const int at1 = (int)fsq_guard(c, wave_reserve(cnt_next + CNT_C1, park && to_c1), cap, G_KB_C1);
+                const int at3 = (int)fsq_guard(c, wave_reserve(cnt_next + CNT_C3, park && !to_c1), cap, G_KB_C3);
                 if (park) {
                     const NtQ qn = ntq(QC_next + (to_c1 ? (long long)at1 : cap - 1 - at3));
                     qn[A_IDX * cap] = pack2(tag, 0);
@@ -1227,9 +1249,9 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
             // accepted -> a new Jacobian (queue A); rejected -> another pass with the same, mutated R (queue B)
             const bool toA = live && status == 0 && accepted, toB = live && status == 0 && !accepted;
             const bool hi = lm_hist > 1;
-            const int atA = wave_reserve(cnt_next + CNT_A, toA);
-            const int atBl = wave_reserve(cnt_next + CNT_BLO, toB && !hi);
-            const int atBh = wave_reserve(cnt_next + CNT_BHI, toB && hi);
+            const int atA = (int)fsq_guard(c, wave_reserve(cnt_next + CNT_A, toA), cap, G_KB_A);
+            const int atBl = (int)fsq_guard(c, wave_reserve(cnt_next + CNT_BLO, toB && !hi), cap, G_KB_BLO);
+            const int atBh = (int)fsq_guard(c, wave_reserve(cnt_next + CNT_BHI, toB && hi), cap, G_KB_BHI);
             if (toA || toB) {
                 const NtQ qn = ntq(toA ? (QA_next + atA) : (QB_next + (hi ? cap - 1 - atBh : (long long)atBl)));
                 qn[A_IDX * cap] = pack2(tag, lm_hist);
@@ -1439,7 +1461,7 @@ static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 // FsqFitQueue (include/fsq.h) keeps an engine alive across batches, so that the long latency-bound tail of one batch
 // (a fit may need 200 sequential iterations) rides along in the full launches of the batches submitted after it.
 namespace {
-enum { CTL_SLOW_TOTAL = 2 * CNT_SET, CTL_SLOW_CNT = 2 * CNT_SET + 1, CTL_F32_NEXT = 2 * CNT_SET + 2, CTL_DONE = 2 * CNT_SET + 8, CTL_INTS = CTL_DONE + FSQ_MAX_TICKETS };
+enum { CTL_SLOW_TOTAL = 2 * CNT_SET, CTL_SLOW_CNT = 2 * CNT_SET + 1, CTL_F32_NEXT = 2 * CNT_SET + 2, CTL_ERR = 2 * CNT_SET + 3, CTL_DONE = 2 * CNT_SET + 8, CTL_INTS = CTL_DONE + FSQ_MAX_TICKETS };
 
 struct RoundsCfg {
     int lm_first = FSQ_LMPAR_FIRST, lm_lo = FSQ_LMPAR_LO, sync_mask = 3, force_slow_mod = 0, force_redo = 0, no_wave_prio = 0, trace = 0;
@@ -1559,7 +1581,7 @@ struct FsqFitQueue {
         SQ = (double*)(ws + o); o += al256(qcap * A_LEN * 8);
         cset[0] = ctl; cset[1] = ctl + CNT_SET;
         cSlow = ctl + CTL_SLOW_CNT;
-        c.slow_total = ctl + CTL_SLOW_TOTAL; c.done = ctl + CTL_DONE;
+        c.slow_total = ctl + CTL_SLOW_TOTAL; c.done = ctl + CTL_DONE; c.err = ctl + CTL_ERR; c.pool = (long long)pool;
         c.tshift = single ? 31 : 32 - FSQ_TICKET_BITS;
         if (!single && pool_ >= (1ull << c.tshift)) return FSQ_ENOTIMPL;
         c.wave_prio = 0; c.force_redo = cfg.force_redo; c.force_slow_mod = cfg.force_slow_mod;
@@ -1678,6 +1700,11 @@ struct FsqFitQueue {
         slow_pending = h_ctl[CTL_SLOW_CNT];
         alive = boundA + hc[CNT_BLO] + hc[CNT_BHI] + hc[CNT_C1] + hc[CNT_C3] + slow_pending;
         g_last_slow.store(h_ctl[CTL_SLOW_TOTAL]);
+        if (h_ctl[CTL_ERR] != 0) {          // a kernel was about to write outside a queue / the pool (fsq_guard): an engine bug, say which
+            fprintf(stderr, "fsq: fit queue invariant %d broken (cap %lld, pool %lld, host bounds: A %lld alive %lld; counters A %d B %d+%d C %d+%d slow %d)\n",
+                    h_ctl[CTL_ERR], (long long)qcap, (long long)pool, boundA, alive, hc[CNT_A], hc[CNT_BLO], hc[CNT_BHI], hc[CNT_C1], hc[CNT_C3], h_ctl[CTL_SLOW_CNT]);
+            return FSQ_EINTERNAL;
+        }
         if (cfg.trace) fprintf(stderr, "round %lld: A=%lld B=%d+%d C=%d+%d slow=%lld total_slow=%d\n", round - 1, boundA, hc[CNT_BLO], hc[CNT_BHI], hc[CNT_C1], hc[CNT_C3], slow_pending, h_ctl[CTL_SLOW_TOTAL]);
         int fin = 0;
         for (auto& t : b) {

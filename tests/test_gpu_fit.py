@@ -217,6 +217,31 @@ def test_every_fit_through_the_slow_queue(env, monkeypatch):
     assert sorted(seen) == [(j, 8 * len(g["table_keys"])) for j in range(3)]
 
 
+def test_workspace_contents_do_not_matter(env, monkeypatch):
+    """The fit must not depend on what the caller's workspace holds: here it is filled with random bits and with 0xFF bytes
+    (NaN patterns) before the call, and every third fit is sent through the slow queue so that the step round meets DEAD
+    queue slots (reserved by the Jacobian round, never filled in: the lanes of such slots compute on whatever the memory held).
+    Round 3's fuzz hit a GPU memory fault exactly there - the sin / cos table was indexed with garbage - once the workspace
+    was recycled memory instead of fresh zero pages; results must be the oracle's bits whatever the workspace held."""
+    torch, N, O = env
+    g, img = load_field("f3_hard_256")
+    rois = np.ascontiguousarray(np.tile(rois_of(img, g["candidates"]), (8, 1)).astype(np.uint16))
+    d = torch.from_numpy(rois.view(np.int16)).cuda()
+    nbytes = N.lib().fsq_fit_workspace_bytes(len(rois))
+    monkeypatch.setenv("FSQ_DEBUG_FORCE_SLOW", "3")
+    for fill in ("random", "ones"):
+        ws = (torch.randint(0, 256, (nbytes,), dtype=torch.uint8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(7))
+              if fill == "random" else torch.full((nbytes,), 255, dtype=torch.uint8, device="cuda"))
+        rows = torch.zeros(len(rois) * 128, dtype=torch.uint8, device="cuda")
+        N.check(N.lib().fsq_fit_rois(d.data_ptr(), len(rois), 0, rows.data_ptr(), ws.data_ptr(), ws.numel(),
+                                     torch.cuda.current_stream().cuda_stream), "fsq_fit_rois")
+        torch.cuda.synchronize()
+        got = rows.cpu().numpy().view(N.ROW_DTYPE)
+        p = np.stack([got[k] for k in ("H", "A", "p2", "p3", "sigma_h", "sigma_w", "theta")], axis=1)
+        assert bits_equal(p, np.tile(g["params"], (8, 1))).all() and np.array_equal(got["status"], np.tile(g["status"], 8)), fill
+    monkeypatch.delenv("FSQ_DEBUG_FORCE_SLOW")
+
+
 def test_square_shortcut_equals_pow(env):
     """qrfac's norm down-dating squares a NumPy scalar, i.e. libm's pow(t, 2.0) (mpfit.py:1816); the Jacobian kernel takes
     t * t wherever fsq_square_is_pow2 holds.  The implication `predicate => pow(t, 2.0) == t * t` on: the ratios the

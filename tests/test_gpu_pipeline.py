@@ -174,3 +174,69 @@ def test_whole_path_entry_point_equals_the_staged_calls():
             torch.cuda.synchronize()
             assert ncand == int(eng.offsets[5].item()) and len(rec) == len(rec0) > 20
             assert torch.equal(rec, rec0) and torch.equal(offs, offs0) and torch.equal(nk, eng.nkeep)
+
+
+def test_engine_buffers_may_hold_anything():
+    """detect -> fit -> consolidate with every workspace / output buffer of the Engine pre-filled with random bits (recycled
+    device memory is not zero): the tables still equal the oracle's."""
+    import torch
+    import oracle as O
+    from fluorosequencingimageanalysis_amd import _native as N, engine as E, pflib, synth
+    O.build()
+    imgs = np.stack([synth.make_field(60 + i, (80, 112), 8 + 5 * i) for i in range(4)])
+    eng = E.Engine(4, 80, 112)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for t in (eng.ws, eng.fit_ws, eng.rows, eng.cand, eng.keep, eng.counts, eng.offsets, eng.nkeep, eng.thr):
+        raw = t.view(torch.uint8)
+        raw.copy_(torch.randint(0, 256, (raw.numel(),), dtype=torch.uint8, device="cuda", generator=gen).reshape(raw.shape))
+    d = E.to_device_u16(imgs)
+    prm = E.detect_params(5, pflib.default_correlation_matrix, 2)
+    eng.run(d, prm, 0.7, 4, N.MODE_REF, True)
+    dicts = pflib._engine_dicts(eng, d)
+    for f in range(4):
+        rows, fits, keep, key = O.find_peptides(imgs[f])
+        assert [tuple(k) for k in key.tolist()] == list(dicts[f])
+        exp = np.stack([rows[keep][k] for k in ("h0", "w0", "H", "A", "sigma_h", "sigma_w", "theta")], axis=1)
+        val = np.array([[float(x) for x in v[:7]] for v in dicts[f].values()]).reshape(-1, 7)
+        assert np.array_equal(val.view(np.uint64), exp.view(np.uint64))
+
+
+def test_fresh_device_memory_may_hold_anything(monkeypatch):
+    """Every device buffer the Python layer allocates with torch.empty is handed out pre-filled with random bits (what a
+    long-lived process gets from the caching allocator): registration, both trackers, photometry and the batch surface still
+    equal the oracle / the undisturbed results."""
+    import torch
+    import oracle as O
+    from fluorosequencingimageanalysis_amd import flexlibrary as fl, pflib, phase_correlate as pc, photometry, synth
+    O.build()
+    rng = np.random.default_rng(9)
+    imgs = np.stack([synth.make_field(80 + i, (96, 96), 10 + 3 * i) for i in range(4)])
+    want_batch = pflib.find_peptides_batch(imgs)
+    ref, reg = imgs[0], np.roll(imgs[0], (3, -2), (0, 1))
+    want_pc = pc.phase_correlate(ref, reg, upsample_factor=20)
+    hw = [np.array(sorted(d), np.int32).reshape(-1, 2) for d in want_batch]
+    want_tr = fl.track_fields([hw], [[(0.0, 0.0)] * 4], (96, 96), 2, 0.0)
+    want_ph = photometry.mexican_hat_photometry_metric(imgs[:1], np.concatenate([np.zeros((len(hw[0]), 1), np.int32), hw[0]], 1))
+    pflib.release_gpu_resources()
+    real_empty = torch.empty
+    gen = torch.Generator(device="cuda").manual_seed(1)
+
+    def dirty_empty(*a, **k):
+        t = real_empty(*a, **k)
+        if t.is_cuda and t.numel():
+            raw = t.view(torch.uint8) if t.is_contiguous() else None
+            if raw is not None:
+                raw.copy_(torch.randint(0, 256, (raw.numel(),), dtype=torch.uint8, device=t.device, generator=gen).reshape(raw.shape))
+        return t
+    monkeypatch.setattr(torch, "empty", dirty_empty)
+    got_batch = pflib.find_peptides_batch(imgs)
+    got_pc = pc.phase_correlate(ref, reg, upsample_factor=20)
+    got_tr = fl.track_fields([hw], [[(0.0, 0.0)] * 4], (96, 96), 2, 0.0)
+    got_ph = photometry.mexican_hat_photometry_metric(imgs[:1], np.concatenate([np.zeros((len(hw[0]), 1), np.int32), hw[0]], 1))
+    monkeypatch.setattr(torch, "empty", real_empty)
+    pflib.release_gpu_resources()
+    assert [list(d) for d in got_batch] == [list(d) for d in want_batch]
+    assert all(np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True) for a, b in zip(got_batch, want_batch) for k in a for x, y in zip(a[k], b[k]))
+    assert tuple(float(x) for x in got_pc) == tuple(float(x) for x in want_pc)
+    assert all(np.array_equal(x, y) if isinstance(x, np.ndarray) else x == y for a, b in zip(got_tr, want_tr) for x, y in zip(a, b))
+    assert np.array_equal(np.asarray(got_ph), np.asarray(want_ph), equal_nan=True)
