@@ -43,8 +43,16 @@ for shape_i in range(10):
                 img = rng.integers(0, int(rng.integers(2, 5000)), (H, W)).astype(np.uint16)
             fs.append(img)
         batches.append(np.stack(fs))
-    prm = E.detect_params(med, pflib.default_correlation_matrix, c_std)
-    d = [E.to_device_u16(b) for b in batches]
+    fmt = N.PIXELS_U16
+    if rng.random() < 0.3:          # fp16 pixel loads: the fields as binary16 (pre-scaled when they exceed its range), the oracle on the truncated values
+        halves = [E.quantise_f16(b)[0] for b in batches]
+        words = [E.as_pixel_fields(h)[0] for h in halves]
+        batches = [E.pixel_values(w, N.PIXELS_F16).astype(np.uint16) for w in words]
+        fmt = N.PIXELS_F16
+    else:
+        words = batches
+    prm = E.detect_params(med, pflib.default_correlation_matrix, c_std, fmt)
+    d = [E.to_device_u16(w) for w in words]
     group = E.StreamPipelineGroup(nf, H, W, queues=2, depth=4, inject_below=int(rng.choice([0, 500, 1 << 40])))
     got = {}
 
@@ -54,6 +62,24 @@ for shape_i in range(10):
     group.run([(x, prm) for x in d], on_done, r2_threshold=r2, radius=rad, py2_round=True)
     cut = group.cut
     group.close()
+    # the whole path as one library call (fsq_find_peptides) on one batch, buffers far too small at first, fewer fields than the
+    # runner was built for: the same tables
+    jb = int(rng.integers(nb))
+    m = int(rng.integers(1, nf + 1))
+    pr = E.PathRunner(nf, H, W, cand_cap=int(rng.integers(1, 64)), record_cap=int(rng.integers(1, 8)))
+    rec, roffs, rnk, _ = pr.run(d[jb][:m], prm, r2, rad, N.MODE_REF, True)
+    rec, roffs, rnk = rec.cpu().numpy(), roffs.cpu().numpy(), rnk.cpu().numpy()
+    for f in range(m):
+        k = 0 if f < cut[1] else 1
+        table, offs, nkeep = got[(jb, k)]
+        ff = f - cut[k]
+        assert rnk[f] == nkeep[ff], ("path runner", shape_i, f)
+        if nkeep[ff] >= 0:
+            mine = E.peak_record_view(rec[roffs[f]:roffs[f + 1]])
+            t = table[offs[ff]:offs[ff + 1]]
+            for name in ("h0", "w0", "H", "A", "sigma_h", "sigma_w", "theta", "rmse", "r2", "s_n", "key_h", "key_w"):
+                x, y = np.ascontiguousarray(mine[name]), np.ascontiguousarray(t[name])
+                assert x.tobytes() == y.tobytes(), ("path runner", shape_i, f, name)
     for j in range(nb):
         for k in range(2):
             table, offs, nkeep = got[(j, k)]
