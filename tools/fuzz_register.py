@@ -53,5 +53,26 @@ for t in range(cases):
     if not ok:
         bad += 1
         print("DIFF case %d: shape %s uf %d kind %d: %r vs %r" % (t, (H, W), uf, kind, tuple(float(x) for x in r), e), flush=True)
-print("registration: %d cases, %d differ from the oracle" % (cases, bad), flush=True)
+# batches: several pairs of one shape in one call (the batched kernels index per-pair peaks, offsets and partial sums)
+nb = 0
+for t in range(cases // 3):
+    H, W = int(rng.integers(4, 200)), int(rng.integers(4, 200))
+    uf = int(rng.choice([1, 10, 20, 100]))
+    k = int(rng.integers(2, 9))
+    refs = rng.integers(0, 4000, (k, H, W)).astype(np.uint16)
+    regs = np.stack([np.roll(refs[i], (int(rng.integers(-H // 2, H // 2 + 1)), int(rng.integers(-W // 2, W // 2 + 1))), (0, 1)) for i in range(k)])
+    regs = np.minimum(regs.astype(np.int64) + rng.integers(0, 40, (k, H, W)), 65535).astype(np.uint16)
+    if rng.random() < 0.3:
+        regs[int(rng.integers(k))] = rng.integers(0, 4000, (H, W))          # one unrelated pair among them
+    got = pc.phase_correlate_batch(refs, regs, uf)
+    for i in range(k):
+        e = O.phase_correlate(refs[i], regs[i], uf)
+        r = got[i]
+        ok = float(r[0]) == e[0] and float(r[1]) == e[1] and abs(float(r[2]) ** 2 - e[2] ** 2) < 1e-9 and \
+            (abs(float(r[3]) - e[3]) < 1e-9 or abs(abs(float(r[3]) - e[3]) - 2 * np.pi) < 1e-9)
+        nb += 1
+        if not ok:
+            bad += 1
+            print("DIFF batch case %d pair %d of %d: shape %s uf %d: %r vs %r" % (t, i, k, (H, W), uf, tuple(float(x) for x in r), e), flush=True)
+print("registration: %d cases + %d pairs in batches, %d differ from the oracle" % (cases, nb, bad), flush=True)
 sys.exit(1 if bad else 0)
