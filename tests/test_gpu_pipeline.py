@@ -227,6 +227,7 @@ def test_fresh_device_memory_may_hold_anything(monkeypatch):
             raw = t.view(torch.uint8) if t.is_contiguous() else None
             if raw is not None:
                 raw.copy_(torch.randint(0, 256, (raw.numel(),), dtype=torch.uint8, device=t.device, generator=gen).reshape(raw.shape))
+                torch.cuda.current_stream(t.device).synchronize()  # (the fill must not race with the buffer's first use on another stream)
         return t
     monkeypatch.setattr(torch, "empty", dirty_empty)
     got_batch = pflib.find_peptides_batch(imgs)
