@@ -36,6 +36,9 @@ namespace {
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
+#ifdef FSQ_DEBUG_HZ
+__device__ unsigned long long g_hz[32];
+#endif
 #ifdef FSQ_PHASE_PROFILE
 __device__ unsigned long long g_rphase[32];
 #define RPH_DECL unsigned long long rph_t0 = clock64(), rph_acc[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};
@@ -349,6 +352,13 @@ FSQ_DEV double kag_dot25(const double* lds, int grp, int off)
 // optimiser turns it into one tree at the end of the kernel and keeps every numerator alive for it)
 #define KA_ROWS(i) do { if (L == 8 && ((i) % 5) == 4) __builtin_amdgcn_sched_barrier(0); } while (0)
 #define KA_PIN(v) do { if (FAST) asm volatile("" : "+v"(v)); } while (0)
+// a guarded operand range was left / a decision could not be settled: the fit goes to the plain-division kernel.  -DFSQ_DEBUG_HZ
+// counts the reasons (fsq_debug_hz; tools/hz_reasons.py)
+#ifdef FSQ_DEBUG_HZ
+#define KA_HZ(code, cond) do { if (cond) { hz = true; if (FAST) atomicAdd(&g_hz[code], 1ull); } } while (0)
+#else
+#define KA_HZ(code, cond) do { if (cond) hz = true; } while (0)
+#endif
 template <bool FAST, int L>
 __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const double* __restrict__ QA, const int* __restrict__ cntA_p,
                                                                     double* __restrict__ QB, int* __restrict__ cnt_cur,
@@ -486,7 +496,7 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
                 const double x2p = xx[2] + hh[2], x3p = xx[3] + hh[3];
                 const double rcx2 = xx[3] * cs - x2p * sn, rcy2 = xx[3] * sn + x2p * cs;
                 const double rcx3 = x3p * cs - xx[2] * sn, rcy3 = x3p * sn + xx[2] * cs;
-                if (FAST) hz = hz || !(__builtin_fabs(x2p) <= 0x1p100) || !(__builtin_fabs(x3p) <= 0x1p100);
+                if (FAST) KA_HZ(0, !(__builtin_fabs(x2p) <= 0x1p100) || !(__builtin_fabs(x3p) <= 0x1p100));
 #pragma unroll 1
                 for (int m = 0; m < MPX; m++) {
                     const int i = cl + L * m;
@@ -529,7 +539,7 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
                 double snt, cst;
                 fsq_sincos(FSQ_PI_180 * (xx[6] + hh[6]), &snt, &cst);
                 const double rcxt = xx[3] * cst - xx[2] * snt, rcyt = xx[3] * snt + xx[2] * cst;
-                if (FAST) hz = hz || !fsq_divisor_in_range(x4p) || !fsq_divisor_in_range(x5p);
+                if (FAST) KA_HZ(1, !fsq_divisor_in_range(x4p) || !fsq_divisor_in_range(x5p));
 #pragma unroll 1
                 for (int m = 0; m < MPX; m++) {
                     const int i = cl + L * m;
@@ -560,7 +570,7 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
                     for (int i = 0; i < FSQ_NPIX; i++) { col[NC - 1][i] = QL((s47 < 7) ? Q_STAGE + 25 * (s47 - 4) : Q_FVEC, i); KA_ROWS(i); }
                 }
             }
-            if (FAST) hz = hz || bad;
+            if (FAST) KA_HZ(2, bad);
             double hcol[NC];
 #pragma unroll
             for (int pass = 0; pass < NC; pass++) {
@@ -581,10 +591,10 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
                 for (int pass = 0; pass < NC; pass++) {
                     ssum[pass] = 0.0;
                     kh[pass] = fsq_divisor(hcol[pass]);
-                    if (FAST) hz = hz || !fsq_divisor_in_range(hcol[pass]);
+                    if (FAST) KA_HZ(3, !fsq_divisor_in_range(hcol[pass]));
                 }
                 // residuals are bounded by 2^16 + x0 + x1, so the numerators below stay under 2^102
-                if (FAST) hz = hz || !(QL(Q_X, 0) <= 0x1p100) || !(QL(Q_X, 1) <= 0x1p100);
+                if (FAST) KA_HZ(4, !(QL(Q_X, 0) <= 0x1p100) || !(QL(Q_X, 1) <= 0x1p100));
 #pragma unroll
                 for (int i = 0; i < FSQ_NPIX; i++) {
                     const double fv = QL(Q_FVEC, i);
@@ -637,12 +647,12 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
                     if (FAST) {
                         // the tracked norms carry error bounds (see the down-dating below): the choice is the reference's
                         // when every other candidate lies clearly below the chosen one (exact values compare exactly)
-                        if (kmax < 0) hz = true;
-                        else {
+                        KA_HZ(5, kmax < 0);
+                        if (kmax >= 0) {
                             const double em = QL(Q_EPS, kmax), low_m = rmax * (1. - em);
                             for (int k = j; k < n7; k++) {
                                 const double ek = QL(Q_EPS, k);
-                                if (k != kmax && (ek != 0 || em != 0) && !(QL(Q_RDIAG, k) * (1. + ek) < low_m)) hz = true;
+                                KA_HZ(6, k != kmax && (ek != 0 || em != 0) && !(QL(Q_RDIAG, k) * (1. + ek) < low_m));
                             }
                         }
                     }
@@ -687,7 +697,7 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
                     const double ajn = QL(Q_TMP, 6);
                     const FsqDivisor kn = fsq_divisor(ajn);
                     int er = 0;
-                    if (FAST) hz = hz || !fsq_divisor_in_range(ajn);
+                    if (FAST) KA_HZ(7, !fsq_divisor_in_range(ajn));
 #pragma unroll
                     for (int m = 0; m < MPX; m++) {
                         const int i = cl + L * m;
@@ -711,7 +721,7 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
 #define REFL(i) QL(Q_DATA, i)
                 const double ajj0 = REFL(0);
                 const FsqDivisor kj = fsq_divisor(ajj0);
-                if (FAST) hz = hz || !fsq_divisor_in_range(ajj0);
+                if (FAST) KA_HZ(8, !fsq_divisor_in_range(ajj0));
 #pragma unroll
                 for (int pass = 0; pass < NC; pass++) {
                     const int slot = cl + L * pass;
@@ -726,7 +736,7 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
                         for (int i = 0; i < FSQ_NPIX; i++) { s += col[pass][i] * REFL(i); KA_ROWS(i); }
                         if (FAST) {     // numerators REFL(i) * s: |REFL(i)| < 4, exponent >= emin_s (or zero)
                             const int es = fsq_expo(s);
-                            hz = hz || (emin_s + es - 2 < -FSQ_DIV_EN) || (es + 2 > FSQ_DIV_EN);
+                            KA_HZ(9, (emin_s + es - 2 < -FSQ_DIV_EN) || (es + 2 > FSQ_DIV_EN));
                         }
 #pragma unroll
                         for (int i = 0; i < FSQ_NPIX; i++) { col[pass][i] = col[pass][i] - fsq_div_sel<FAST>(REFL(i) * s, kj); KA_ROWS(i); }
@@ -770,19 +780,19 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
                             const bool exact = (e0 == 0) && fsq_square_is_pow2(t, sq, lo);
                             const double v = 1. - sq;
                             const double dv = exact ? 0. : sq * (2. * e0 + 8. * U) + 2. * U;      // bound of |v - v_ref|
-                            if (!(v == v)) hz = true;
-                            if (!exact && !(__builtin_fabs(v) > dv)) hz = true;                     // sign of 1 - t^2 not settled
+                            KA_HZ(10, !(v == v));
+                            KA_HZ(11, !exact && !(__builtin_fabs(v) > dv));                     // sign of 1 - t^2 not settled
                             const double rk1 = rk * fsq_sqrt(np_max2(v, 0.));
                             double e1 = 0.;
                             if (!exact && v > 0) e1 = e0 + 0.6 * dv * __builtin_amdgcn_rcp(v) + 4. * U;
-                            if (!(e1 < 1e-3)) hz = true;
+                            KA_HZ(12, !(e1 < 1e-3));
                             const double temp = rk1 / QL(Q_WA, p);
                             const double q = 0.05 * temp * temp;
                             if (e1 == 0) need = (q <= FSQ_MACHEP);
                             else {
                                 const double qe = 2. * e1 + 8. * U;
                                 if (q * (1. + qe) <= FSQ_MACHEP) need = true;
-                                else if (!(q * (1. - qe) > FSQ_MACHEP)) hz = true;
+                                else KA_HZ(14, !(q * (1. - qe) > FSQ_MACHEP));
                             }
                             if (c.force_redo) need = true;
                             if (!need) { QL(Q_RDIAG, p) = rk1; QL(Q_EPS, p) = e1; }
@@ -856,7 +866,7 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
             // ---- finish it (gradient test) ... ---------------------------------------------------------------
             if (FAST) {
                 // one verdict per fit: any lane out of range sends the whole fit to the plain-division kernel
-                hz = hz || (emin < -FSQ_DIV_EN);
+                KA_HZ(13, (emin < -FSQ_DIV_EN));
                 if (c.force_slow_mod > 0 && (idx % c.force_slow_mod) == 0) hz = true;
                 const unsigned long long m = __ballot(hz);
                 qhz = ((m >> gbase) & ((1ull << L) - 1ull)) != 0;
@@ -909,6 +919,7 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
 #undef REFL
 #undef KA_ROWS
 #undef KA_PIN
+#undef KA_HZ
 #pragma pop_macro("QL")
 
 // ---------------------------------------------------------------------------------------------------
@@ -1439,6 +1450,15 @@ extern "C" int fsq_selftest_division(const double* d_num, const double* d_den, i
 }
 
 extern "C" int64_t fsq_fit_last_slow_count(void) { return g_last_slow.load(); }
+#ifdef FSQ_DEBUG_HZ
+extern "C" int fsq_debug_hz(unsigned long long* out32, int reset)
+{
+    FSQ_HIP_CHECK(hipDeviceSynchronize());
+    FSQ_HIP_CHECK(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_hz), sizeof(unsigned long long) * 32));
+    if (reset) { unsigned long long z[32] = {0}; FSQ_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_hz), z, sizeof(z))); }
+    return FSQ_OK;
+}
+#endif
 
 #ifdef FSQ_PHASE_PROFILE
 extern "C" int fsq_debug_rphase(unsigned long long* out32, int reset)
