@@ -84,7 +84,15 @@ def main():
                          "(phase correlation of consecutive cycle frames, upsample_factor 20) - pairs/s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the H2D-inclusive and dict-materialising side measurements")
+    ap.add_argument("--materialise", action="store_true",
+                    help="N > 1: every step's gathered peak RECORDS (378 B per peak, not just the 128 B rows) go to rank 0 and "
+                         "rank 0 builds the reference's dicts from them inside the timed region (distributed.py's dict form)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: this process becomes the launcher of N ranks (one per GPU) and touches
+        # neither the GPU nor torch.cuda itself; rank 0's JSON line is relayed and checked against the request
+        sys.exit(launch_ranks(a))
 
     import torch
     import torch.distributed as dist
@@ -102,8 +110,14 @@ def main():
 
     rank, world, local = D.init_from_env()
     assert rank == env_rank
-    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    if world != a.gpus:         # never report a line for another job size than the one asked for
+        raise SystemExit("bench.py: --gpus %d but the process group has %d rank(s) (WORLD_SIZE); launch with `python bench.py "
+                         "--gpus %d` or torch.distributed.run --nproc-per-node %d" % (a.gpus, world, a.gpus, a.gpus))
     assert torch.cuda.is_available(), "bench.py needs a GPU; the HIP path has no CPU fallback"
+    backend = dist.get_backend() if world > 1 else "none"
+    if world > torch.cuda.device_count() and backend != "gloo":
+        raise SystemExit("bench.py: %d ranks but %d GPU(s) visible (FSQ_DIST_BACKEND=gloo rehearses the N > 1 path on fewer GPUs)"
+                         % (world, torch.cuda.device_count()))
     local = local % torch.cuda.device_count()      # (more ranks than GPUs only in the gloo rehearsal of the N > 1 path)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -150,6 +164,7 @@ def main():
             traffic = traffic * (a.fields / 1024.0)
         out = {
             "metric": "psf_lm_fits_per_sec", "value": fits_per_s, "unit": "fits/s", "n_gpus": world,
+            "ranks": (dist.get_world_size() if world > 1 else 1), "backend": backend,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[1]: %d synthetic %dx%d uint16 fields per GPU, %d spots each, "
@@ -184,6 +199,53 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def check_rank0_line(line, gpus):
+    """The launcher's acceptance test of what rank 0 printed: one JSON object whose n_gpus / ranks equal the request."""
+    j = json.loads(line)
+    if j.get("n_gpus") != gpus or j.get("ranks", gpus) != gpus:
+        raise ValueError("rank 0 reported n_gpus=%r ranks=%r for --gpus %d" % (j.get("n_gpus"), j.get("ranks"), gpus))
+    return j
+
+
+def launch_ranks(a, argv=None, run=None):
+    """`python bench.py --gpus N` without a torchrun environment: start N ranks of this script (torch.distributed.run, one
+    process per GPU, rendezvous on 127.0.0.1) as CHILD processes - this process has not touched the GPU and never does -,
+    relay rank 0's JSON line and return the children's exit code.  A line that does not carry n_gpus == N is an error (the
+    reference's own pool never silently shrinks either: pflib.py:1082-1099 starts exactly num_processes workers)."""
+    import subprocess
+    argv = list(sys.argv[1:] if argv is None else argv)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    p = (run or subprocess.run)(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in (p.stdout or "").splitlines() if ln.startswith("{")]
+    for ln in (p.stdout or "").splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if p.returncode != 0:
+        print("bench.py: the %d-rank job failed with exit code %d" % (a.gpus, p.returncode), file=sys.stderr)
+        return p.returncode or 1
+    if len(lines) != 1:
+        print("bench.py: expected one JSON line from rank 0, got %d" % len(lines), file=sys.stderr)
+        return 1
+    try:
+        check_rank0_line(lines[0], a.gpus)
+    except ValueError as e:
+        print("bench.py: %s" % e, file=sys.stderr)
+        return 1
+    print(lines[0], flush=True)
+    return 0
 
 
 REG_BYTES_PER_PX = 2 * (2 + 8) + 2 * 4 * 8 + (16 + 16 + 8) + 4 * 8 + 8 + 2 * 8      # = 180
@@ -276,14 +338,20 @@ def run_stream(a, torch, dist, D, E, N, d_img, imgs, prm, dev, rank, world):
     Q = len(group.pipes)
     kept = [0] * Q
     box = _queue.Queue()
+    built = [0]
+    from fluorosequencingimageanalysis_amd import pflib as pflib_mod
 
     def on_done(j, k, eng, total):
         kept[k] = eng.nkeep[eng.n_fields]           # (device scalar; read after the run)
         if world > 1:
-            table = eng.kept_table()[0]
+            if a.materialise:                       # the full peak records (FsqRow + fit_img + sub_img) and the per-field counts
+                table = eng.peak_records(d_img[group.cut[k]:group.cut[k + 1]])[0]
+                nk = eng.nkeep[:eng.n_fields].clone().reshape(-1, 1)
+            else:
+                table, nk = eng.kept_table()[0], None
             ev = torch.cuda.Event()
             ev.record()
-            box.put((j, k, table, ev))
+            box.put((j, k, table, ev, nk))
 
     def steps(n):
         res, errs = [None], []
@@ -306,9 +374,13 @@ def run_stream(a, torch, dist, D, E, N, d_img, imgs, prm, dev, rank, world):
                     if item is None:
                         raise errs[0]
                     ready[(item[0], item[1])] = item[2:]
-                table, ev = ready.pop((j, k))
+                table, ev, nk = ready.pop((j, k))
                 torch.cuda.current_stream().wait_event(ev)
-                D.gather_tables(table, 0)
+                tab, _ = D.gather_tables(table, 0)
+                if nk is not None:                  # --materialise: rank 0 turns every gathered table into the reference's dicts
+                    cnt, _ = D.gather_tables(nk, 0)
+                    if rank == 0:
+                        built[0] += len(pflib_mod.records_to_dicts(tab.cpu().numpy(), cnt.cpu().numpy().reshape(-1)))
         th.join()
         if errs:
             raise errs[0]
@@ -332,6 +404,10 @@ def run_stream(a, torch, dist, D, E, N, d_img, imgs, prm, dev, rank, world):
     how = ("the steps are streamed through %d fit queue(s) on their own streams, the fields of a step split between them "
            "(continuous batching: at most %d batches in flight per queue, next batch submitted below %d live fits; %s rounds "
            "for %d steps)" % (Q, group.pipes[0].depth, group.pipes[0].inject_below, rounds, a.steps))
+    if world > 1:
+        how += ("; every step's %s gathered to rank 0 inside the timed region"
+                % ("peak records (378 B per peak) and built into the reference's dicts there (--materialise: %d field dicts)" % built[0]
+                   if a.materialise else "kept rows (128 B per peak)"))
 
     def cand_tables():
         e = E.Engine(a.fields, a.size, a.size, device=dev, fit_workspace=False)

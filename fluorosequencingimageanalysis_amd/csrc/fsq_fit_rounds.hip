@@ -128,6 +128,15 @@ FSQ_DEV int wave_reserve(int* counter, bool want)
     return base + __popcll(m & ((1ull << lane) - 1ull));
 }
 
+// ... and the position checked against the list's capacity - for the lanes that will WRITE there only: a lane that does not
+// append gets the counter value behind the wave's reservation, which equals the capacity when the list becomes exactly full
+// and is no violation.
+FSQ_DEV long long wave_reserve_checked(const Ctx& c, int* counter, bool want, long long limit, int code)
+{
+    const int at = wave_reserve(counter, want);
+    return want ? fsq_guard(c, at, limit, code) : 0;
+}
+
 // One batch of candidates: where its pixels come from, which pool slots it owns, where its rows go.
 struct BatchArgs {
     const uint16_t* src; const int32_t* cand; int H, W; long long n; int from_image;
@@ -219,7 +228,7 @@ __global__ void __launch_bounds__(256) kinit(Ctx c, BatchArgs b, double* __restr
     const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool ok = i0 < b.n;
     const long long i = ok ? i0 : 0;            // idle lanes of the last block recompute fit 0 and store nothing
-    const long long pos = fsq_guard(c, wave_reserve(cntA, ok && !b.no_queue), c.cap, G_KINIT_POS);     // appended behind whatever the queue already holds
+    const long long pos = wave_reserve_checked(c, cntA, ok && !b.no_queue, c.cap, G_KINIT_POS);     // appended behind whatever the queue already holds
     if (b.n <= 0) return;
     const long long slot = fsq_guard(c, b.base + i, c.pool, G_KINIT_SLOT);
     double v[FSQ_NPIX];
@@ -405,7 +414,7 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
                 if ((long long)nlo + nhi > cap) atomicMax(c.err, (int)G_KA_OVERLAP);
             }
         }
-        const long long at = __shfl((int)fsq_guard(c, b_hi ? (long long)(cap - 1) - at_hi : (long long)at_lo, cap, b_hi ? G_KA_BHI : G_KA_BLO), gbase);
+        const long long at = __shfl((active && cl == 0) ? (int)fsq_guard(c, b_hi ? (long long)(cap - 1) - at_hi : (long long)at_lo, cap, b_hi ? G_KA_BHI : G_KA_BLO) : 0, gbase);
         const int idx = tag_slot(c, tag);
         const bool fresh = active && (nfev == 0);
         double llim1 = 0., fnorm = 0., xnorm = 0., delta = 0., par_in = 0.;
@@ -884,7 +893,7 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
         {
             bool go = active && (status == 0);
             if (FAST) {
-                int sat = (int)fsq_guard(c, wave_reserve(slow_cnt, qhz && cl == 0), cap, G_KA_SLOW);
+                int sat = (int)wave_reserve_checked(c, slow_cnt, qhz && cl == 0, cap, G_KA_SLOW);
                 sat = __shfl(sat, gbase);
                 if (qhz) for (int f = cl; f < A_LEN; f += L) nt_st(SQ + (size_t)sat + f * cap, qa[f * cap]);
                 go = go && !qhz;
@@ -1017,28 +1026,48 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
         bool live = (base + lane) < cnt;
         const int p_in = live ? (base + lane) : base;
         const NtQ qb = ntq((resume ? QC : QB) + ((seg & 1) ? cap - 1 - p_in : p_in));
-        int tag, dummy, niter, nfev, ipvt_i;
-        unpack2(qb[A_IDX * cap], &tag, &dummy);
-        if (tag == -1) { live = false; tag = 0; }        // a slot the Jacobian round reserved and did not need (loads below stay in bounds)
-        unpack2(qb[A_ITER * cap], &niter, &nfev);
-        unpack2(qb[B_IPVT * cap], &ipvt_i, &dummy);
-        const unsigned ipvt = (unsigned)ipvt_i;
-        QuadLm q;
-#pragma unroll
-        for (int i = 0; i < FSQ_NP; i++)
-#pragma unroll
-            for (int k = 0; k < FSQ_NP; k++) q.r[i][k] = (k >= i) ? qb[(B_R + rpk(i, k)) * cap] : 0.0;
-        double xq[FSQ_NP];
-#pragma unroll
-        for (int k = 0; k < FSQ_NP; k++) {
-            q.qtf[k] = qb[(B_QTF + k) * cap]; q.dg[k] = qb[(A_DIAG + k) * cap]; q.sdiag[k] = qb[(B_SDIAG + k) * cap];
-            xq[k] = qb[(A_X + k) * cap];
+        // DEAD slots (tag -1: reserved early by the Jacobian round and not needed, only their tag is written) and the idle lanes
+        // of a list's last tile hold no fit: they do not read the record at all and work on a fixed, valid stand-in instead
+        // (an identity R, a zero right-hand side, the start point of a fit), so that no address, table index or LDS offset of
+        // this kernel is ever derived from memory nobody wrote.  Nothing such a lane computes is stored (every store below is
+        // under `live`).
+        int tag = 0, dummy, niter = 1, nfev = 1, ipvt_i = 0x76543210;
+        {
+            int t;
+            unpack2(qb[A_IDX * cap], &t, &dummy);
+            if (t == -1) live = false;
+            if (live) tag = t;
         }
-        const double llim1 = qb[A_LLIM1 * cap];
+        QuadLm q;
+        double xq[FSQ_NP];
+        double llim1 = 0., fnorm = 1., par = 0., delta = 1., xnorm = 1., fnorm1;
+        if (live) {
+            unpack2(qb[A_ITER * cap], &niter, &nfev);
+            unpack2(qb[B_IPVT * cap], &ipvt_i, &dummy);
+#pragma unroll
+            for (int i = 0; i < FSQ_NP; i++)
+#pragma unroll
+                for (int k = 0; k < FSQ_NP; k++) q.r[i][k] = (k >= i) ? (double)qb[(B_R + rpk(i, k)) * cap] : 0.0;
+#pragma unroll
+            for (int k = 0; k < FSQ_NP; k++) {
+                q.qtf[k] = qb[(B_QTF + k) * cap]; q.dg[k] = qb[(A_DIAG + k) * cap]; q.sdiag[k] = qb[(B_SDIAG + k) * cap];
+                xq[k] = qb[(A_X + k) * cap];
+            }
+            llim1 = qb[A_LLIM1 * cap];
+            fnorm = qb[A_FNORM * cap]; par = qb[A_PAR * cap]; delta = qb[A_DELTA * cap]; xnorm = qb[A_XNORM * cap];
+        } else {
+            const double x0[FSQ_NP] = {100., 1000., 2.5, 2.5, 1., 1., 0.};
+#pragma unroll
+            for (int i = 0; i < FSQ_NP; i++)
+#pragma unroll
+                for (int k = 0; k < FSQ_NP; k++) q.r[i][k] = (k == i) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < FSQ_NP; k++) { q.qtf[k] = 0.; q.dg[k] = 1.; q.sdiag[k] = 0.; xq[k] = x0[k]; }
+        }
+        const unsigned ipvt = (unsigned)ipvt_i;
         // (gnorm is only copied through and tested once at the end: it is read where it is needed instead of being
         // carried through lmpar - the kernel is at its register limit)
 #define KB_GNORM() kb_late_load(qb[B_GNORM * cap])
-        double fnorm = qb[A_FNORM * cap], par = qb[A_PAR * cap], delta = qb[A_DELTA * cap], xnorm = qb[A_XNORM * cap], fnorm1;
 #pragma unroll
         for (int k = 0; k < FSQ_NP; k++) myscr[k * 64] = q.dg[k];
 #pragma unroll
@@ -1049,12 +1078,12 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
         {
             QuadLmparSt st;
             if (!resume) quadlm_lmpar_begin<ALIASED, 64>(q, myscr, ipvt, delta, par, st);
-            else {
+            else if (live) {
                 int it, dm;
                 unpack2(qb[C_LMIT * cap], &it, &dm);
                 st.par = par; st.parl = qb[C_PARL * cap]; st.paru = qb[C_PARU * cap]; st.fp = qb[C_FP * cap];
                 st.iter = it; st.done = false;
-            }
+            } else { st.par = 0.; st.parl = 0.; st.paru = 0.; st.fp = 0.; st.iter = 10; st.done = true; }
             RPH_MARK(7)
             quadlm_lmpar_run<ALIASED, 64>(q, myscr, ipvt, delta, st, lm_limit);
             par = st.par;
@@ -1063,8 +1092,8 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
                 // unfinished: park the fit (R / sdiag / par state as they stand) for the next round's launch
                 const bool park = live && !st.done;
                 const bool to_c1 = (st.iter < lims.lim[2]);            // (C 1 tiles run to lim[2], C 3 tiles to the end: always progress)
-                const int at1 = (int)fsq_guard(c, wave_reserve(cnt_next + CNT_C1, park && to_c1), cap, G_KB_C1);
-                const int at3 = (int)fsq_guard(c, wave_reserve(cnt_next + CNT_C3, park && !to_c1), cap, G_KB_C3);
+                const int at1 = (int)wave_reserve_checked(c, cnt_next + CNT_C1, park && to_c1, cap, G_KB_C1);
+                const int at3 = (int)wave_reserve_checked(c, cnt_next + CNT_C3, park && !to_c1, cap, G_KB_C3);
                 if (park) {
                     const NtQ qn = ntq(QC_next + (to_c1 ? (long long)at1 : cap - 1 - at3));
                     qn[A_IDX * cap] = pack2(tag, 0);
@@ -1260,9 +1289,9 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
             // accepted -> a new Jacobian (queue A); rejected -> another pass with the same, mutated R (queue B)
             const bool toA = live && status == 0 && accepted, toB = live && status == 0 && !accepted;
             const bool hi = lm_hist > 1;
-            const int atA = (int)fsq_guard(c, wave_reserve(cnt_next + CNT_A, toA), cap, G_KB_A);
-            const int atBl = (int)fsq_guard(c, wave_reserve(cnt_next + CNT_BLO, toB && !hi), cap, G_KB_BLO);
-            const int atBh = (int)fsq_guard(c, wave_reserve(cnt_next + CNT_BHI, toB && hi), cap, G_KB_BHI);
+            const int atA = (int)wave_reserve_checked(c, cnt_next + CNT_A, toA, cap, G_KB_A);
+            const int atBl = (int)wave_reserve_checked(c, cnt_next + CNT_BLO, toB && !hi, cap, G_KB_BLO);
+            const int atBh = (int)wave_reserve_checked(c, cnt_next + CNT_BHI, toB && hi, cap, G_KB_BHI);
             if (toA || toB) {
                 const NtQ qn = ntq(toA ? (QA_next + atA) : (QB_next + (hi ? cap - 1 - atBh : (long long)atBl)));
                 qn[A_IDX * cap] = pack2(tag, lm_hist);

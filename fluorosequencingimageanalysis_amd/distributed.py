@@ -56,7 +56,7 @@ def lpt_partition(weights, n_parts):
     return parts
 
 
-def gather_tables(local_rows, dst=0):
+def gather_tables(local_rows, dst=0, _force=False):
     """Variable-length gather of row tables (2-D uint8/any dtype tensors, same trailing shape) to `dst`.
 
     all_gather of the per-rank row counts, then direct point-to-point receives into slices of one
@@ -64,7 +64,7 @@ def gather_tables(local_rows, dst=0):
     on dst and (None, counts) elsewhere.  With world size 1 it returns its input."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not _force):
         return local_rows, [int(local_rows.shape[0])]
     world, rank = dist.get_world_size(), dist.get_rank()
     if dist.get_backend() == "gloo" and local_rows.is_cuda:      # (CPU rehearsal of the N > 1 path: gloo moves host memory)
@@ -110,7 +110,7 @@ def _all_ranks_ok(local_error):
         raise RuntimeError("rank %d failed: %s" % bad[0])
 
 
-def find_peptides_sharded(images, partition="lpt", dst=0, n_fields=None, **find_peptides_parameters):
+def find_peptides_sharded(images, partition="lpt", dst=0, n_fields=None, output="dicts", **find_peptides_parameters):
     """pflib.find_peptides over n same-shaped fields sharded over the ranks of the process group (one process per GPU).
     Every rank calls it with the same arguments.
 
@@ -119,13 +119,26 @@ def find_peptides_sharded(images, partition="lpt", dst=0, n_fields=None, **find_
     partition='lpt' balances the fields by candidate count with the reference's longest-processing-time rule
     (pflib.parallel_image_batch, pflib.py:1043-1069: candidates are counted first - every rank counts a round-robin share in
     one detection pass, 2 % of the work of a fit pass - then the fields are dealt out); 'round_robin' gives field i to rank
-    i mod world.  Each rank streams its share through the same pipeline as pflib.find_peptides_batch; the only exchange is
-    the gather of the peak records to `dst` (RCCL p2p, gather_tables).  Returns the list of n dicts (identical to
-    pflib.find_peptides_batch on one GPU) on `dst` and None on the other ranks.  A rank that fails makes every rank raise."""
+    i mod world.  Each rank streams its share through the same pipeline as pflib.find_peptides_batch; its peak records stay
+    in HBM from the kernels that write them to the send (no host copy in between when the backend is RCCL).
+
+    output - what comes back, and what it costs (the reference's pool returns nothing at all: its workers write files,
+    pflib.py:1082-1106):
+      'records'  on `dst`: (records uint8[k, engine.PEAK_RECORD_BYTES] of ALL fields in field order, int32[n] peaks per field
+                 (-1: the re-key assertion of pflib.py:518 fired), pixel format) - pflib.find_peptides_records' form, None on
+                 the other ranks.  The only exchange is the point-to-point gather of the records (gather_tables); no Python
+                 object per peak exists anywhere, so this form scales with the ranks.
+      'local'    on EVERY rank: {global field index: dict} for the fields the rank fitted - the dicts are built where the
+                 fields were fitted (every rank's interpreter works on its own share) and nothing travels.
+      'dicts'    on `dst`: the list of n dicts pflib.find_peptides_batch returns on one GPU (built by dst's interpreter from the
+                 gathered records: about 4 500 fields/s whatever the number of ranks - the compatibility form).
+    A rank that fails makes every rank raise."""
     import torch
     import torch.distributed as dist
     from . import engine as E
     from . import pflib
+    if output not in ("dicts", "records", "local"):
+        raise ValueError("output must be 'dicts', 'records' or 'local'")
     world, rank = world_size(), get_rank()
     if callable(images):
         if n_fields is None:
@@ -136,9 +149,14 @@ def find_peptides_sharded(images, partition="lpt", dst=0, n_fields=None, **find_
         if stack.ndim != 3:
             raise ValueError("images must have shape (n, H, W)")
         loader, n = (lambda idx: stack[idx]), len(stack)
-    if world == 1:
-        return pflib.find_peptides_batch(loader(list(range(n))), **find_peptides_parameters)
+    if world == 1 and not find_peptides_parameters.get("_force_collectives"):
+        everything = loader(list(range(n)))
+        if output == "records":
+            return pflib.find_peptides_records(everything, **find_peptides_parameters)
+        dicts = pflib.find_peptides_batch(everything, **find_peptides_parameters)
+        return dict(enumerate(dicts)) if output == "local" else dicts
     fp = dict(find_peptides_parameters)
+    fp.pop("_force_collectives", None)          # (tests: run the exchange code with a process group of one rank)
     if fp.get("consolidation_radius", 4) < 2:
         raise ValueError("consolidation_radius must be at least 2")
     if fp.get("fit_type", "gauss") != "gauss":
@@ -154,7 +172,7 @@ def find_peptides_sharded(images, partition="lpt", dst=0, n_fields=None, **find_
                 held[i] = a
         return np.stack([held[i] for i in idx]) if idx else None
 
-    err, parts, rec, counts, fmt = None, None, None, None, 0
+    err, parts, rec, counts, fmt, local = None, None, None, None, 0, None
     try:
         if partition == "lpt":
             mine = shard_fields(n, rank, world)
@@ -174,27 +192,46 @@ def find_peptides_sharded(images, partition="lpt", dst=0, n_fields=None, **find_
     try:
         for i in [i for i in held if i not in mine]:
             del held[i]
-        if mine:
-            rec, counts, fmt = pflib.find_peptides_records(load(mine), **fp)
+        if output == "local":
+            local = dict(zip(mine, pflib.find_peptides_batch(load(mine), errors='return', **fp))) if mine else {}
+        elif mine:
+            rec, counts, fmt = pflib.find_peptides_records(load(mine), device=True, **fp)
         else:
-            rec, counts = np.zeros((0, E.PEAK_RECORD_BYTES), np.uint8), np.zeros(0, np.int32)
+            rec, counts = torch.zeros((0, E.PEAK_RECORD_BYTES), dtype=torch.uint8, device=dev), np.zeros(0, np.int32)
         held.clear()
     except Exception as e:      # noqa: BLE001
         err = e
     _all_ranks_ok(err)
-    t_rec = torch.from_numpy(np.ascontiguousarray(rec))
+    if output == "local":
+        for d in local.values():
+            if isinstance(d, Exception):
+                raise d
+        return local
+    # the exchange: the records as they sit in HBM (gloo, the CPU rehearsal, moves host memory: gather_tables copies them)
     t_cnt = torch.from_numpy(np.ascontiguousarray(counts, dtype=np.int32).reshape(-1, 1))
     if not gloo:
-        t_rec, t_cnt = t_rec.to(dev), t_cnt.to(dev)
-    table, _ = gather_tables(t_rec, dst)
-    fields, _ = gather_tables(t_cnt, dst)
+        t_cnt = t_cnt.to(dev)
+    table, _ = gather_tables(rec, dst, _force=True)
+    fields, _ = gather_tables(t_cnt, dst, _force=True)
     fmts = [None] * world
     dist.all_gather_object(fmts, int(fmt) if mine else None)
     if rank != dst:
         return None
     fmt = next((f for f in fmts if f is not None), 0)
-    dicts = pflib.records_to_dicts(table.cpu().numpy(), fields.cpu().numpy().reshape(-1), fmt)
     order = [i for p in parts for i in p]                  # global field index of every gathered per-field entry
+    by_rank = fields.cpu().numpy().reshape(-1).astype(np.int32)
+    if output == "records":
+        # gathered order (rank by rank) -> global field order: one gather of record rows on the device
+        offs = np.concatenate([[0], np.cumsum(np.maximum(by_rank, 0))])
+        where = np.empty(n, np.int64)
+        where[order] = np.arange(n)
+        idx = (np.concatenate([np.arange(offs[where[i]], offs[where[i] + 1]) for i in range(n)])
+               if n else np.zeros(0, np.int64))
+        same = bool(len(idx) == 0 or (np.diff(idx) == 1).all())
+        if not same:
+            table = table[torch.from_numpy(idx).to(table.device)]
+        return table.cpu().numpy(), by_rank[where], fmt
+    dicts = pflib.records_to_dicts(table.cpu().numpy(), by_rank, fmt)
     out = [None] * n
     for k, i in enumerate(order):
         out[i] = dicts[k]

@@ -253,6 +253,32 @@ class _RunnerClosed(Exception):
     pass
 
 
+# The interpreter's thread switch interval is process-global: the batch runners shorten it while they run (their pipeline
+# thread needs the interpreter for a few calls per chunk; while the worker builds dicts it would wait a whole interval - 5 ms by
+# default - for each of them).  Runs of different runners may overlap, so the original value is kept once, with a count of
+# the runs in progress, and restored when the last of them ends (a per-call save / restore could leave it short).
+_SWITCH = {"n": 0, "saved": None, "lock": threading.Lock()}
+BATCH_SWITCH_INTERVAL = 1e-4
+
+
+def _switch_interval_acquire():
+    import sys
+    with _SWITCH["lock"]:
+        if _SWITCH["n"] == 0:
+            _SWITCH["saved"] = sys.getswitchinterval()
+            sys.setswitchinterval(BATCH_SWITCH_INTERVAL)
+        _SWITCH["n"] += 1
+
+
+def _switch_interval_release():
+    import sys
+    with _SWITCH["lock"]:
+        _SWITCH["n"] -= 1
+        if _SWITCH["n"] == 0 and _SWITCH["saved"] is not None:
+            sys.setswitchinterval(_SWITCH["saved"])
+            _SWITCH["saved"] = None
+
+
 def _run_cached_runner(key, factory, *args, **kw):
     """runner.run(...) on the cached runner of `key`; a runner another thread's call has just evicted (and closed) is replaced."""
     while True:
@@ -307,11 +333,13 @@ class _BatchRunner:
                 if self.pipe is not None:
                     self.pipe.close()
 
-    def run(self, words, fmt, prm, r_2_threshold, radius, on_chunk=None, raw=False):
+    def run(self, words, fmt, prm, r_2_threshold, radius, on_chunk=None, raw=False, device=False):
         """words: uint16[n, H, W] (host).  -> list of n dicts / AssertionError instances.  on_chunk(first, dicts), if given, is
         called (in the worker thread) as soon as the dicts of fields first .. first + len(dicts) - 1 exist.
         raw=True: -> (peak records uint8[k, engine.PEAK_RECORD_BYTES] in field order, int32[n] peaks per field, -1 where the
-        re-key assertion fired) instead of dicts - the form the multi-GPU gather ships."""
+        re-key assertion fired) instead of dicts - the form the multi-GPU gather ships.  raw=True, device=True: the records stay
+        where fsq_find_peptides' kernels wrote them - a uint8 DEVICE tensor (torch) instead of a host array; only the per-field
+        counts come to the host (the RCCL gather sends device memory: no D2H -> H2D bounce, distributed.py)."""
         import queue as _queue
         import sys
         torch, per = self.torch, self.per
@@ -394,12 +422,27 @@ class _BatchRunner:
             if errs:
                 raise errs[0]
 
+        stop = threading.Event()        # set when the call is over (normally or not): the stager leaves at its next wait
+
+        def put_staged(item):
+            while not stop.is_set():
+                try:
+                    staged.put(item, timeout=0.05)
+                    return True
+                except _queue.Full:
+                    pass
+            return False
+
         def stage():        # (own thread) copies the chunks into the pinned staging buffers ahead of the pipeline
             try:
                 for c in range(n_chunks):
                     part = words[first[c]:first[c + 1]]
                     i = c % 4
-                    self.pin_free[i].wait()                 # (the consumer of the chunk last staged here has issued its upload ...)
+                    while not self.pin_free[i].wait(0.05):  # (the consumer of the chunk last staged here has issued its upload ...)
+                        if stop.is_set():                   # (... or the GPU side has failed and nobody ever will)
+                            return
+                    if stop.is_set():
+                        return
                     self.pin_free[i].clear()
                     if self.pin_ev[i] is not None:
                         self.pin_ev[i].synchronize()        # (... and the upload is done)
@@ -407,11 +450,12 @@ class _BatchRunner:
                     host[:len(part)] = part
                     if len(part) < per and n_lanes == 0:    # (pipeline engines have a fixed field count: the last chunk is filled up with copies of its last field)
                         host[len(part):] = part[-1]
-                    staged.put((c, i) if n_lanes > 0 else i)
+                    if not put_staged((c, i) if n_lanes > 0 else i):
+                        return
                 if n_lanes > 0:
-                    staged.put(None)
+                    put_staged(None)
             except BaseException as e:      # noqa: BLE001 - handed to the pipeline thread
-                staged.put(e)
+                put_staged(e)
 
         def jobs():
             for c in range(n_chunks):
@@ -428,7 +472,7 @@ class _BatchRunner:
             with torch.cuda.device(self.dev):
                 ev.synchronize()
                 if raw:
-                    rec_host = rec.cpu().numpy()
+                    rec_host = rec if device else rec.cpu().numpy()
                 else:       # through a pinned buffer that is re-used (this thread works one chunk at a time): no fresh pages
                     k = rec.shape[0]
                     if self.rec_pin is None or self.rec_pin.shape[0] < k:
@@ -487,8 +531,7 @@ class _BatchRunner:
             stager = threading.Thread(target=stage, daemon=True)
             # (the pipeline thread needs the interpreter for a few calls per chunk; while the worker builds dicts it would
             # wait a whole switch interval - 5 ms by default - for each of them)
-            interval = sys.getswitchinterval()
-            sys.setswitchinterval(1e-4)
+            _switch_interval_acquire()
             try:
                 stager.start()
                 if n_lanes > 0:
@@ -496,12 +539,11 @@ class _BatchRunner:
                 else:
                     self.pipe.run(jobs(), on_done, r_2_threshold, radius, PY2_ROUND)
             finally:
-                sys.setswitchinterval(interval)
-                while stager.is_alive():                    # (only after a failure: let it run out)
-                    try:
-                        staged.get(timeout=0.1)
-                    except _queue.Empty:
-                        pass
+                _switch_interval_release()
+                stop.set()                                  # (after a failure the stager may be waiting for a buffer or for room
+                stager.join()                               # in the queue: both waits look at `stop`, so it leaves within 50 ms)
+                for e in self.pin_free:
+                    e.set()
                 pool.shutdown(wait=True)
         for f in futures:
             f.result()                                      # re-raises what the worker raised
@@ -512,6 +554,11 @@ class _BatchRunner:
             for c in range(n_chunks):
                 k = int(np.maximum(out[c][1][:max(0, min(per, n - c * per))], 0).sum())
                 recs.append(out[c][0][:k])
+            if device:
+                with torch.cuda.device(self.dev):
+                    for r in recs:          # (allocated on the pipeline's side stream, read by the concatenation on this thread's)
+                        r.record_stream(torch.cuda.current_stream(self.dev))
+                    return (torch.cat(recs) if recs else torch.zeros((0, _engine.PEAK_RECORD_BYTES), dtype=torch.uint8, device=self.dev)), counts
             return np.concatenate(recs) if recs else np.zeros((0, _engine.PEAK_RECORD_BYTES), np.uint8), counts
         return out[:n]
 
@@ -571,10 +618,11 @@ def find_peptides_batch(images, median_filter_size=5, correlation_matrix=default
 
 
 def find_peptides_records(images, median_filter_size=5, correlation_matrix=default_correlation_matrix, c_std=2,
-                          r_2_threshold=0.7, consolidation_radius=4, solver='reference', **unused):
+                          r_2_threshold=0.7, consolidation_radius=4, solver='reference', device=False, **unused):
     """find_peptides over a stack, results as the byte tables the multi-GPU gather ships instead of dicts:
     -> (records uint8[k, engine.PEAK_RECORD_BYTES] of all fields in order, int32[n] peaks per field (-1: the re-key
-    assertion of pflib.py:518 fired for that field), pixel format).  records_to_dicts turns them into find_peptides' dicts."""
+    assertion of pflib.py:518 fired for that field), pixel format).  records_to_dicts turns them into find_peptides' dicts.
+    device=True: the records are returned as a torch uint8 tensor in HBM (never copied to the host)."""
     mode = _solver_mode(solver)
     if consolidation_radius < 2:
         raise ValueError("consolidation_radius must be at least 2")
@@ -584,11 +632,14 @@ def find_peptides_records(images, median_filter_size=5, correlation_matrix=defau
         raise ValueError("images must have shape (n, H, W)")
     n, H, W = imgs.shape
     if n == 0 or H < 5 or W < 5:
+        if device:
+            torch = _engine._torch()
+            return torch.zeros((0, _engine.PEAK_RECORD_BYTES), dtype=torch.uint8, device="cuda"), np.zeros(n, np.int32), fmt
         return np.zeros((0, _engine.PEAK_RECORD_BYTES), np.uint8), np.zeros(n, np.int32), fmt
     n_chunks = max(1, -(-(n * H * W) // CHUNK_PIXELS))
     per = -(-n // n_chunks)
     rec, counts = _run_cached_runner(("batch", _device_key(), per, H, W, mode), lambda: _BatchRunner(per, H, W, mode),
-                                     imgs, fmt, prm, r_2_threshold, consolidation_radius, raw=True)
+                                     imgs, fmt, prm, r_2_threshold, consolidation_radius, raw=True, device=bool(device))
     return rec, counts, fmt
 
 

@@ -37,6 +37,20 @@ def _worker(rank, world, port, q, partition):
     from fluorosequencingimageanalysis_amd import distributed as D
     torch.cuda.set_device(0)
     D.init_from_env(backend="gloo")
+    if partition in ("records", "local"):      # the forms that scale: byte tables on rank 0 / dicts where the fields were fitted
+        from fluorosequencingimageanalysis_amd import pflib
+        built = []
+        real = pflib._records_to_dicts
+        pflib._records_to_dicts = lambda *a, **k: built.append(1) or real(*a, **k)
+        out = D.find_peptides_sharded(_fields(), partition="lpt", output=partition, c_std=2)
+        if partition == "records":
+            assert not built, "output='records' must not create a Python object per peak on any rank"
+            q.put((rank, out))
+        else:
+            q.put((rank, out))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if partition == "loader":                  # a per-rank loader: the rank only ever holds the fields it asks for
         stack, asked = _fields(), set()
 
@@ -87,6 +101,95 @@ def test_sharded_equals_single_rank(partition):
         p.join(timeout=120)
         assert p.exitcode == 0
     _same_dicts(got, single)
+
+
+def _run_two(partition):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, partition)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return got
+
+
+def test_sharded_records_output_gathers_bytes_only():
+    """output='records': rank 0 receives the byte table of all fields in field order + the per-field counts - equal to
+    find_peptides_records on one GPU, byte for byte -, rank 1 gets None, and no rank builds a dict."""
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from fluorosequencingimageanalysis_amd import pflib
+    rec1, counts1, fmt1 = pflib.find_peptides_records(_fields(), c_std=2)
+    got = _run_two("records")
+    assert got[1] is None
+    rec, counts, fmt = got[0]
+    assert fmt == fmt1 and np.array_equal(counts, counts1) and rec.dtype == np.uint8
+    assert rec.shape == rec1.shape and np.array_equal(rec, rec1)
+    _same_dicts(pflib.records_to_dicts(rec, counts, fmt), pflib.find_peptides_batch(_fields(), c_std=2))
+
+
+def test_sharded_local_output_builds_dicts_where_the_fields_were_fitted():
+    """output='local': every rank returns {global field index: dict} for its own share; together they are the single-rank
+    list, and the shares are the LPT partition."""
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from fluorosequencingimageanalysis_amd import distributed as D, pflib
+    single = pflib.find_peptides_batch(_fields(), c_std=2)
+    got = _run_two("local")
+    assert set(got[0]) and set(got[1]) and not (set(got[0]) & set(got[1])) and set(got[0]) | set(got[1]) == set(range(10))
+    parts = D._partition([int(x) for x in pflib.count_candidates(_fields(), c_std=2)], 2, "lpt")
+    assert sorted(got[0]) == parts[0] and sorted(got[1]) == parts[1]
+    merged = dict(got[0], **got[1])
+    _same_dicts([merged[i] for i in range(10)], single)
+
+
+def _rccl_worker(q):
+    sys.path.insert(0, ROOT)
+    port = _free_port()
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    from fluorosequencingimageanalysis_amd import distributed as D
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    assert dist.get_backend() == "nccl"
+    rec = D.find_peptides_sharded(_fields(), partition="lpt", output="records", c_std=2, _force_collectives=True)
+    dicts = D.find_peptides_sharded(_fields(), partition="round_robin", output="dicts", c_std=2, _force_collectives=True)
+    # the variable-length gather itself on device tensors (counts all_gather on the GPU; one rank: no peer to receive from)
+    t = torch.arange(12, dtype=torch.uint8, device="cuda").reshape(3, 4)
+    table, counts = D.gather_tables(t, 0, _force=True)
+    assert counts == [3] and torch.equal(table, t) and table.is_cuda
+    torch.cuda.synchronize()
+    q.put((rec, dicts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_runs_the_exchange_code_on_device_tensors():
+    """The `nccl` (= RCCL) branches of the sharded path - the candidate-count all_reduce and the counts all_gather on DEVICE
+    tensors, the records handed to the gather as they sit in HBM - executed for real: a process group of ONE rank over RCCL on
+    the test box's one GPU (two RCCL ranks cannot share a device), the exchange code forced on.  What a one-rank group
+    cannot exercise is the point-to-point send itself; that is covered over gloo by the two-rank tests above."""
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import torch.multiprocessing as mp
+    from fluorosequencingimageanalysis_amd import pflib
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(q,))
+    p.start()
+    (rec, counts, fmt), dicts = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    rec1, counts1, fmt1 = pflib.find_peptides_records(_fields(), c_std=2)
+    assert np.array_equal(rec, rec1) and np.array_equal(counts, counts1) and fmt == fmt1
+    _same_dicts(dicts, pflib.find_peptides_batch(_fields(), c_std=2))
 
 
 def test_sharded_world1_is_batch():
