@@ -195,3 +195,46 @@ def test_fit_queue_capacity_and_errors(env):
     for e in engs:
         assert no_keys(e.rows[:total].cpu().numpy().tobytes()) == no_keys(ref_rows)
     q.close()
+
+
+@pytest.mark.parametrize("force_slow", [0, 1])
+def test_fit_queue_filled_exactly_to_its_capacity(env, monkeypatch, force_slow):
+    """A queue of 256 positions holding exactly 256 live fits, submitted as 100 + 156 (neither a multiple of 64): every list
+    becomes exactly full - in round 1 every fit sits in B lo - and the lanes that append nothing must not trip the capacity
+    guard (they were handed the counter value behind the wave's reservation, == cap, and reported FSQ_EINTERNAL).
+    With striped lists (round 4) only four of the sixteen stripes own a chunk of such a small queue: all the others turn their
+    appends away and the overflow into the following stripes is what places every fit.  force_slow: every fit through the
+    plain-division kernel in every round (its appends go through the same reservation)."""
+    torch, N, E, pflib, synth = env
+    if force_slow:
+        monkeypatch.setenv("FSQ_DEBUG_FORCE_SLOW", "1")
+    H = W = 96
+    prm = E.detect_params(5, pflib.default_correlation_matrix, 2)
+    d = E.to_device_u16(np.stack([synth.make_field(170 + i, (H, W), 25) for i in range(2)]))
+    eng = E.Engine(2, H, W)
+    total = eng.run(d, prm)
+    assert total >= 256
+    ref = eng.rows[:256].cpu().numpy().view(N.ROW_DTYPE).reshape(-1).copy()
+    e1, e2 = E.Engine(2, H, W, fit_workspace=False), E.Engine(2, H, W, fit_workspace=False)
+    for e in (e1, e2):
+        assert e.detect(d, prm) == total
+    torch.cuda.synchronize()
+    q = E.FitQueue(pool_slots=512, queue_cap=256)
+    assert q.queue_cap == 256
+    t1 = q.submit(d, 2, H, W, e1.cand, 100, e1.rows)
+    t2 = q.submit(d, 2, H, W, e2.cand[100:], 156, e2.rows)
+    assert t1 is not None and t2 is not None and q.alive == 256
+    assert q.submit(d, 2, H, W, e2.cand, 1, e2.rows) is None          # not one more
+    cur = torch.cuda.current_stream()
+    done = set()
+    while len(done) < 2:
+        q.advance(0, 0)                                                # (raises RuntimeError on FSQ_EINTERNAL)
+        for t in (t1, t2):
+            if t not in done and q.take(t, cur):
+                done.add(t)
+    torch.cuda.synchronize()
+    got = np.concatenate([e1.rows[:100].cpu().numpy().view(N.ROW_DTYPE).reshape(-1), e2.rows[:156].cpu().numpy().view(N.ROW_DTYPE).reshape(-1)])
+    for x in (got, ref):
+        x["key_h"] = x["key_w"] = -1
+    assert got.tobytes() == ref.tobytes()
+    q.close()
