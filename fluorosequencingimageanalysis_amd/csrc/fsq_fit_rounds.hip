@@ -60,28 +60,13 @@ __device__ unsigned long long g_rphase[32];
 // Indexed by candidate: a compact 64-byte copy of the 25 ROI pixels (kinit), the model's 25 exponentials E at the current
 // point (written on acceptance, read by kA, which rebuilds fvec = data - (x0 + x1 E) from them), the final result, the ROI
 // statistics.
-// Lists and their tail counters.  A round moves every fit from one list to another: queue A (input of kA), B lo / B hi (input of
-// kB, binned by the number of Newton iterations lmpar took for this fit LAST time: <= 1 / more - the count is sticky per fit,
-// oracle statistics in DESIGN.md - so that a wave's lanes mostly finish lmpar together), C 1 / C 3 (fits parked in the middle
-// of lmpar after 1 resp. FSQ_LMPAR_FIRST iterations, picked up by the NEXT round's launch); each list has its own array, in
-// ping/pong copies (one set read, one written per round).
-// STRIPES (round 4).  A wave appends with ONE atomicAdd on the list's tail counter (wave_reserve) - and every atomic on one
-// 128-byte line is executed one after the other by the memory side, 88 per microsecond chip-wide however many waves issue them
-// (tools/ubench/atomic_rate.hip; two counters in one line: still 88; 16 lines: 1 120).  With one tail per list the 7 million
-// appends of a bench step were 60 ms of serialised atomics in kA and as much in kB: both kernels' times rose linearly with
-// extra dummy atomics.  So every list is FSQ_STRIPES sub-lists ("stripes") with their own tails, each stripe's
-// five counters in a cache line of its own; a block appends to the stripe its index hashes to.  Stripe k's elements are laid
-// out in CHUNKS of 64 positions, chunk c of stripe k being chunk c * FSQ_STRIPES + k of the array: element i of stripe k sits at
-// position ((i / 64) * FSQ_STRIPES + k) * 64 + i % 64.  A consumer tile of 64 consecutive positions is therefore one chunk of
-// one stripe and only has to compare its element numbers with that stripe's count; a wave's reservation is contiguous inside a
-// chunk (coalesced as before).  A stripe that is full (its last chunk would lie beyond the capacity) overflows into the next
-// one (stripe_reserve), so the capacity condition stays "all elements of a list <= cap" whatever the balance between stripes.
-#ifndef FSQ_STRIPES
-#define FSQ_STRIPES 16
-#endif
-enum { NSTRIPE = FSQ_STRIPES, CNT_LINE = 32 /* ints: one 128-byte line per stripe */ };
-static_assert((NSTRIPE & (NSTRIPE - 1)) == 0 && NSTRIPE >= 1 && NSTRIPE <= 16, "FSQ_STRIPES: a power of two, at most 16 (kB reads 4 lists x stripes with one wave)");
-enum { CNT_A = 0, CNT_BLO = 1, CNT_BHI = 2, CNT_C1 = 3, CNT_C3 = 4, CNT_SET = NSTRIPE * CNT_LINE };
+// Counters of one ping/pong set of queues (8 ints): fits waiting in queue A, in the two lists of queue B and the two of queue C.
+// Queues B and C each hold TWO lists in one array, one growing from position 0 upwards and one from cap - 1 downwards:
+//   B lo / hi   input of the step round, binned by the number of Newton iterations lmpar took for this fit LAST time
+//               (<= 1 / more: the count is sticky per fit, oracle statistics in DESIGN.md) - a wave's lanes then mostly finish
+//               lmpar together instead of all waiting for the slowest
+//   C 1 / 3     fits parked in the middle of lmpar after 1 resp. 3 iterations; they are picked up by the NEXT round's launch
+enum { CNT_A = 0, CNT_BLO = 1, CNT_BHI = 2, CNT_C1 = 3, CNT_C3 = 4, CNT_SET = 8 };
 enum { Q_EPS = Q_WA3 };           // kA, during qrfac: relative error bounds of the tracked column norms (by logical position)
 enum { A_IDX = 0, A_X = 1, A_DIAG = 8, A_LLIM1 = 15, A_FNORM = 16, A_PAR = 17, A_DELTA = 18, A_XNORM = 19, A_ITER = 20,
        A_LEN = 21,
@@ -109,8 +94,7 @@ struct Ctx {
     long long pool;           // by-candidate slots
     int* err;                 // first invariant a kernel found broken (0: none) - see fsq_guard
     int* slow_total;          // statistics: fits that went through the plain-division kernel
-    int* done;                // [NSTRIPE][CNT_LINE >= FSQ_MAX_TICKETS]: terminated fits per batch in flight, counted per stripe
-    unsigned salt;            // changes every round: which stripe a block appends to (stripe_of_block)
+    int* done;                // [FSQ_MAX_TICKETS]: terminated fits per batch in flight
     int tshift;               // a record's tag = slot | ticket << tshift (one 32-bit word: the kernels are at the register limit)
     int wave_prio;            // late rounds: raise the waves' issue priority (they share CUs with another lane's big kernels)
     int force_redo;           // debug: take qrfac's norm re-computation branch at every step (FSQ_DEBUG_FORCE_NORM_RECOMPUTE)
@@ -121,7 +105,7 @@ struct Ctx {
 // queues from upper bounds it keeps itself (FsqFitQueue::alive), and if one of those bounds were ever wrong the write would
 // land outside the workspace - a memory fault at best, silent damage at worst.  A position out of range is recorded (the
 // largest code wins; FsqFitQueue::look turns it into FSQ_EINTERNAL) and replaced by position 0, which is inside.
-enum { G_KINIT_POS = 1, G_KINIT_SLOT = 2, G_KA_BLO = 3, G_KA_BHI = 4, G_KA_SLOW = 6, G_KB_C1 = 7, G_KB_C3 = 8, G_KB_A = 9,
+enum { G_KINIT_POS = 1, G_KINIT_SLOT = 2, G_KA_BLO = 3, G_KA_BHI = 4, G_KA_OVERLAP = 5, G_KA_SLOW = 6, G_KB_C1 = 7, G_KB_C3 = 8, G_KB_A = 9,
        G_KB_BLO = 10, G_KB_BHI = 11 };
 FSQ_DEV long long fsq_guard(const Ctx& c, long long v, long long limit, int code)
 {
@@ -153,50 +137,6 @@ FSQ_DEV long long wave_reserve_checked(const Ctx& c, int* counter, bool want, lo
     return want ? fsq_guard(c, at, limit, code) : 0;
 }
 
-// ---- striped lists (see the layout comment at the top) ------------------------------------------------------------------
-// elements stripe k of a list can hold: its chunks are k, k + NSTRIPE, ... below cap / 64 (cap is a multiple of 64)
-FSQ_DEV int stripe_limit(long long cap, int k) { return (int)(((cap >> 6) - k + NSTRIPE - 1) / NSTRIPE) << 6; }
-FSQ_DEV int stripe_count(const int* set, int list, int k, long long cap)        // (a full stripe's tail keeps counting the appends it turned away)
-{
-    const int n = set[k * CNT_LINE + list], lim = stripe_limit(cap, k);
-    return n < lim ? n : lim;
-}
-FSQ_DEV long long stripe_pos(int k, int i) { return ((((long long)(i >> 6) * NSTRIPE) + k) << 6) | (long long)(i & 63); }
-// The stripe a block appends to: a multiplicative hash of the block index and the round, so that neither a period in the
-// data nor the order of the input tiles can favour a stripe (consecutive blocks visit the stripes in a low-discrepancy order).
-FSQ_DEV int stripe_of_block(unsigned b, unsigned salt)
-{
-    if (NSTRIPE == 1) return 0;
-    constexpr int LOG = NSTRIPE >= 16 ? 4 : NSTRIPE >= 8 ? 3 : NSTRIPE >= 4 ? 2 : 1;
-    return (int)(((b + salt * 0x3c6ef372u) * 0x9e3779b1u) >> (32 - LOG));       // the TOP bits: the golden-ratio sequence's low discrepancy lives there
-}
-// inclusive prefix sum over the 64 lanes of a wave
-FSQ_DEV int wave_prefix_incl(int v)
-{
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(v, d); v += (lane >= d) ? t : 0; }
-    return v;
-}
-// Reserve one element of list `list` for every lane with `want` set, in the stripe k0 - or, for the lanes a full stripe turns
-// away, in the following ones.  Returns the lane's queue position; a lane no stripe has room for (the list's capacity is
-// exhausted: the host's bound was wrong) reports `code` and gets position 0, which is inside.
-FSQ_DEV long long stripe_reserve(const Ctx& c, int* set, int list, int k0, bool want, int code)
-{
-    long long pos = 0;
-    int k = k0;
-    for (int attempt = 0; attempt < NSTRIPE; attempt++) {
-        if (__ballot(want) == 0ull) break;
-        const int i = wave_reserve(set + k * CNT_LINE + list, want);
-        const bool ok = want && i < stripe_limit(c.cap, k);
-        if (ok) pos = stripe_pos(k, i);
-        want = want && !ok;
-        k = (k + 1) & (NSTRIPE - 1);
-    }
-    if (want) atomicMax(c.err, code);
-    return pos;
-}
-
 // One batch of candidates: where its pixels come from, which pool slots it owns, where its rows go.
 struct BatchArgs {
     const uint16_t* src; const int32_t* cand; int H, W; long long n; int from_image;
@@ -207,9 +147,8 @@ struct BatchArgs {
 };
 
 // Count the lanes with `term` set into their batches' done counters: one atomic per wave per batch present.
-FSQ_DEV void wave_mark_done(int* done_all, int stripe, bool term, int ticket)
+FSQ_DEV void wave_mark_done(int* done, bool term, int ticket)
 {
-    int* done = done_all + stripe * CNT_LINE;       // (one line of FSQ_MAX_TICKETS counters per stripe; the host adds them up)
     unsigned long long m = __ballot(term);
     const int lane = threadIdx.x & 63;
     while (m) {
@@ -284,13 +223,12 @@ FSQ_DEV void roi_compact(const Ctx& c, long long idx, double* d)
     for (int k = 0; k < FSQ_NPIX; k++) d[k] = (double)((w[k >> 1] >> (16 * (k & 1))) & 0xffffu);
 }
 
-__global__ void __launch_bounds__(256) kinit(Ctx c, BatchArgs b, double* __restrict__ QA, int* __restrict__ cset)
+__global__ void __launch_bounds__(256) kinit(Ctx c, BatchArgs b, double* __restrict__ QA, int* __restrict__ cntA)
 {
     const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool ok = i0 < b.n;
     const long long i = ok ? i0 : 0;            // idle lanes of the last block recompute fit 0 and store nothing
-    // appended behind whatever queue A already holds (every wave of the block to its own stripe)
-    const long long pos = stripe_reserve(c, cset, CNT_A, stripe_of_block(blockIdx.x * 4u + (threadIdx.x >> 6), c.salt), ok && !b.no_queue, G_KINIT_POS);
+    const long long pos = wave_reserve_checked(c, cntA, ok && !b.no_queue, c.cap, G_KINIT_POS);     // appended behind whatever the queue already holds
     if (b.n <= 0) return;
     const long long slot = fsq_guard(c, b.base + i, c.pool, G_KINIT_SLOT);
     double v[FSQ_NPIX];
@@ -431,8 +369,8 @@ FSQ_DEV double kag_dot25(const double* lds, int grp, int off)
 #define KA_HZ(code, cond) do { if (cond) hz = true; } while (0)
 #endif
 template <bool FAST, int L>
-__global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const double* __restrict__ QA,
-                                                                    double* __restrict__ QBlo, double* __restrict__ QBhi, int* __restrict__ cnt_cur,
+__global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const double* __restrict__ QA, const int* __restrict__ cntA_p,
+                                                                    double* __restrict__ QB, int* __restrict__ cnt_cur,
                                                                     double* __restrict__ SQ, int* __restrict__ slow_cnt,
                                                                     int* __restrict__ next_counters)
 {
@@ -444,38 +382,14 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
     const int lane = threadIdx.x, grp = lane / L, cl = lane % L, gbase = lane - cl;
     const int n7 = FSQ_NP;
     if (c.wave_prio) __builtin_amdgcn_s_setprio(3);
-    const long long cap = c.cap;
-    const int stride = gridDim.x * G;
-    int base = blockIdx.x * G, my_stripe = 0;
-    int cntA;
-    if (FAST) {
-        // Queue A is striped (see the top of the file).  The list's tiles are the chunks of its stripes one stripe after the
-        // other - a prefix sum over the stripes' chunk counts tells which chunk of which stripe block b works on - so the
-        // grid the host sizes from an upper bound of the list's TOTAL (+ one partial chunk per stripe) covers every element
-        // however unevenly the stripes are filled.
-        constexpr int TPC = 64 / G;                                            // tiles per chunk
-        const int n_k = (lane < NSTRIPE) ? stripe_count(cnt_cur, CNT_A, lane, cap) : 0;
-        const int ch = (n_k + 63) >> 6;
-        const int incl = wave_prefix_incl(ch);
-        const int cb = blockIdx.x / TPC, sub = blockIdx.x % TPC;
-        // (block 0 also zeroes the counters of the next round: nobody reads or appends to them during kA)
-        if (blockIdx.x == 0)
-            for (int x = threadIdx.x; x < CNT_SET; x += 64) next_counters[x] = 0;
-        if (cb >= __builtin_amdgcn_readlane(incl, 63)) return;
-        const int k = __popcll(__ballot(incl <= cb));                         // the stripe whose chunks contain number cb
-        const int cc = cb - (__builtin_amdgcn_readlane(incl, k) - __builtin_amdgcn_readlane(ch, k));      // ... its chunk number cc
-        const int first = (cc << 6) + sub * G;                                 // element number of the tile's first position
-        const int left = __builtin_amdgcn_readlane(n_k, k) - first;
-        base = (int)stripe_pos(k, first);
-        cntA = base + (left > 0 ? left : 0);                                    // position p of the tile is live iff p < cntA
-        my_stripe = stripe_of_block(blockIdx.x, c.salt);
-    } else {
-        cntA = *slow_cnt;
-        if (blockIdx.x == 0 && threadIdx.x == 0 && cntA > 0) atomicAdd(c.slow_total, cntA);
-        my_stripe = stripe_of_block(blockIdx.x, c.salt);
-    }
+    const int cntA = FAST ? *cntA_p : *slow_cnt;
+    if (!FAST && blockIdx.x == 0 && threadIdx.x == 0 && cntA > 0) atomicAdd(c.slow_total, cntA);
+    if (FAST && blockIdx.x == 0 && threadIdx.x < CNT_SET) next_counters[threadIdx.x] = 0;
     double col[NC][FSQ_NPIX];
     RPH_DECL
+    const long long cap = c.cap;
+    const int stride = gridDim.x * G;
+    int base = blockIdx.x * G;
     if (base >= cntA) return;
     do {
         RPH_MARK(0)
@@ -491,9 +405,16 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
         unpack2(__shfl(rec[A_ITER / L], gbase + A_ITER % L), &niter, &nfev);
         // this fit's queue-B slot (see above), in the list its lmpar history selects
         const bool b_hi = hist > 1;
-        const long long at_lo = stripe_reserve(c, cnt_cur, CNT_BLO, my_stripe, active && cl == 0 && !b_hi, G_KA_BLO);
-        const long long at_hi = stripe_reserve(c, cnt_cur, CNT_BHI, my_stripe, active && cl == 0 && b_hi, G_KA_BHI);
-        const long long at = __shfl((int)(b_hi ? at_hi : at_lo), gbase);
+        const int at_lo = wave_reserve(cnt_cur + CNT_BLO, active && cl == 0 && !b_hi);
+        const int at_hi = wave_reserve(cnt_cur + CNT_BHI, active && cl == 0 && b_hi);
+        if (active && cl == 0) {      // (two lists in one array, growing towards each other)
+            if (!b_hi) fsq_guard(c, at_lo, cap, G_KA_BLO); else fsq_guard(c, at_hi, cap, G_KA_BHI);
+            if ((long long)at_lo + (long long)at_hi + 2 > cap && (at_lo > 0 || at_hi > 0)) {
+                const int nlo = b_hi ? cnt_cur[CNT_BLO] : at_lo + 1, nhi = b_hi ? at_hi + 1 : cnt_cur[CNT_BHI];
+                if ((long long)nlo + nhi > cap) atomicMax(c.err, (int)G_KA_OVERLAP);
+            }
+        }
+        const long long at = __shfl((active && cl == 0) ? (int)fsq_guard(c, b_hi ? (long long)(cap - 1) - at_hi : (long long)at_lo, cap, b_hi ? G_KA_BHI : G_KA_BLO) : 0, gbase);
         const int idx = tag_slot(c, tag);
         const bool fresh = active && (nfev == 0);
         double llim1 = 0., fnorm = 0., xnorm = 0., delta = 0., par_in = 0.;
@@ -967,7 +888,7 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
                 c.out[idx] = o;
             }
         }
-        wave_mark_done(c.done, my_stripe, active && status != 0 && cl == 0 && !qhz, tag_ticket(c, tag));
+        wave_mark_done(c.done, active && status != 0 && cl == 0 && !qhz, tag_ticket(c, tag));
         // ---- ... or hand it over to the step round (the queue-B slot reserved at the top) --------------------------------
         {
             bool go = active && (status == 0);
@@ -977,7 +898,7 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
                 if (qhz) for (int f = cl; f < A_LEN; f += L) nt_st(SQ + (size_t)sat + f * cap, qa[f * cap]);
                 go = go && !qhz;
             }
-            const NtQ qb = ntq((b_hi ? QBhi : QBlo) + at);
+            const NtQ qb = ntq(QB + at);
             if (go) {
                 for (int e = cl; e < 28; e += L) {
                     int i = 0, rem = e;
@@ -1076,15 +997,11 @@ FSQ_DEV bool kb_trial_gauss(const double* p, double* myscr)
 FSQ_DEV double kb_late_load(const NtRef r) { asm volatile("" ::: "memory"); return (double)r; }
 
 struct KbLimits { int lim[4]; };        // lmpar iteration limits of the four kinds of tiles: B lo, B hi, C 1, C 3
-struct KbQueues {                       // the step round's lists: in[] / out[] by kind of tile (0 B lo, 1 B hi, 2 C 1, 3 C 3)
-    const double* in[4];
-    double* out[4];
-    double* out_a;                      // queue A of the next round
-};
-FSQ_DEV int kb_list_of_seg(int seg) { return seg == 0 ? CNT_BLO : seg == 1 ? CNT_BHI : seg == 2 ? CNT_C1 : CNT_C3; }
 template <bool ALIASED>
-__global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, KbQueues Q, const int* __restrict__ cnt_cur, int* __restrict__ cnt_next,
-                                                            KbLimits lims)
+__global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double* __restrict__ QB, const double* __restrict__ QC,
+                                                  const int* __restrict__ cnt_cur,
+                                                  double* __restrict__ QA_next, double* __restrict__ QB_next, double* __restrict__ QC_next,
+                                                  int* __restrict__ cnt_next, KbLimits lims)
 {
     __shared__ double scr[32 * 64];
     if (c.wave_prio) __builtin_amdgcn_s_setprio(3);
@@ -1095,28 +1012,20 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, KbQueues Q, c
     {
         // One launch works off all four input lists, one 64-fit tile per block, the long-running kinds first: fits parked after
         // 3 iterations (they run up to 7 more), B hi (3 iterations, then parked), fits parked after 1 iteration, B lo.
-        // Every list is NSTRIPE stripes (see the top of the file).  The launch's tiles are the chunks of all (list, stripe) pairs
-        // one pair after the other, the long-running kinds of list first; lane p fetches the count of pair p and a prefix sum
-        // over the pairs' chunk counts tells which chunk of which pair block b works on.  The host's grid - an upper bound of
-        // the fits alive / 64 + one partial chunk per pair - therefore covers every element however the stripes are filled.
-        const int pseg = (lane / NSTRIPE) == 0 ? 3 : (lane / NSTRIPE) == 1 ? 1 : (lane / NSTRIPE) == 2 ? 2 : 0;      // kind of list of pair `lane`
-        const int cntv = (lane < 4 * NSTRIPE) ? stripe_count(cnt_cur, kb_list_of_seg(pseg), lane % NSTRIPE, cap) : 0;
-        const int chv = (cntv + 63) >> 6;
-        const int incl = wave_prefix_incl(chv);
-        const int b = blockIdx.x;
-        if (b >= __builtin_amdgcn_readlane(incl, 63)) return;
-        const int pair = __popcll(__ballot(incl <= b));
-        const int cc = b - (__builtin_amdgcn_readlane(incl, pair) - __builtin_amdgcn_readlane(chv, pair));            // chunk number within the stripe
-        const int seg = (pair / NSTRIPE) == 0 ? 3 : (pair / NSTRIPE) == 1 ? 1 : (pair / NSTRIPE) == 2 ? 2 : 0;
+        int b = blockIdx.x, seg, cnt;
+        const int n_lo = cnt_cur[CNT_BLO], n_hi = cnt_cur[CNT_BHI], n_c1 = cnt_cur[CNT_C1], n_c3 = cnt_cur[CNT_C3];
+        if (b < (n_c3 + 63) / 64) { seg = 3; cnt = n_c3; }
+        else if ((b -= (n_c3 + 63) / 64) < (n_hi + 63) / 64) { seg = 1; cnt = n_hi; }
+        else if ((b -= (n_hi + 63) / 64) < (n_c1 + 63) / 64) { seg = 2; cnt = n_c1; }
+        else if ((b -= (n_c1 + 63) / 64) < (n_lo + 63) / 64) { seg = 0; cnt = n_lo; }
+        else return;
         const bool resume = seg >= 2;               // (wave-uniform)
         const int lm_limit = lims.lim[seg];
-        const long long base = stripe_pos(pair % NSTRIPE, cc << 6);          // the tile = chunk cc of stripe pair % NSTRIPE of that list
-        const int cnt = __builtin_amdgcn_readlane(cntv, pair) - (cc << 6);     // live elements of this chunk (>= 1)
-        const int my_stripe = stripe_of_block(blockIdx.x, c.salt);
+        const int base = b * 64;
         RPH_MARK(0)
-        bool live = lane < cnt;
-        const long long p_in = live ? (base + lane) : base;
-        const NtQ qb = ntq(Q.in[seg] + p_in);
+        bool live = (base + lane) < cnt;
+        const int p_in = live ? (base + lane) : base;
+        const NtQ qb = ntq((resume ? QC : QB) + ((seg & 1) ? cap - 1 - p_in : p_in));
         // DEAD slots (tag -1: reserved early by the Jacobian round and not needed, only their tag is written) and the idle lanes
         // of a list's last tile hold no fit: they do not read the record at all and work on a fixed, valid stand-in instead
         // (an identity R, a zero right-hand side, the start point of a fit), so that no address, table index or LDS offset of
@@ -1183,10 +1092,10 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, KbQueues Q, c
                 // unfinished: park the fit (R / sdiag / par state as they stand) for the next round's launch
                 const bool park = live && !st.done;
                 const bool to_c1 = (st.iter < lims.lim[2]);            // (C 1 tiles run to lim[2], C 3 tiles to the end: always progress)
-                const long long at1 = stripe_reserve(c, cnt_next, CNT_C1, my_stripe, park && to_c1, G_KB_C1);
-                const long long at3 = stripe_reserve(c, cnt_next, CNT_C3, my_stripe, park && !to_c1, G_KB_C3);
+                const int at1 = (int)wave_reserve_checked(c, cnt_next + CNT_C1, park && to_c1, cap, G_KB_C1);
+                const int at3 = (int)wave_reserve_checked(c, cnt_next + CNT_C3, park && !to_c1, cap, G_KB_C3);
                 if (park) {
-                    const NtQ qn = ntq(to_c1 ? Q.out[2] + at1 : Q.out[3] + at3);
+                    const NtQ qn = ntq(QC_next + (to_c1 ? (long long)at1 : cap - 1 - at3));
                     qn[A_IDX * cap] = pack2(tag, 0);
 #pragma unroll
                     for (int k = 0; k < FSQ_NP; k++) {
@@ -1375,16 +1284,16 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, KbQueues Q, c
             o.status = status; o.niter = niter; o.nfev = nfev; o.pad = 0;
             c.out[tag_slot(c, tag)] = o;
         }
-        wave_mark_done(c.done, my_stripe, live && status != 0, tag_ticket(c, tag));
+        wave_mark_done(c.done, live && status != 0, tag_ticket(c, tag));
         {
             // accepted -> a new Jacobian (queue A); rejected -> another pass with the same, mutated R (queue B)
             const bool toA = live && status == 0 && accepted, toB = live && status == 0 && !accepted;
             const bool hi = lm_hist > 1;
-            const long long atA = stripe_reserve(c, cnt_next, CNT_A, my_stripe, toA, G_KB_A);
-            const long long atBl = stripe_reserve(c, cnt_next, CNT_BLO, my_stripe, toB && !hi, G_KB_BLO);
-            const long long atBh = stripe_reserve(c, cnt_next, CNT_BHI, my_stripe, toB && hi, G_KB_BHI);
+            const int atA = (int)wave_reserve_checked(c, cnt_next + CNT_A, toA, cap, G_KB_A);
+            const int atBl = (int)wave_reserve_checked(c, cnt_next + CNT_BLO, toB && !hi, cap, G_KB_BLO);
+            const int atBh = (int)wave_reserve_checked(c, cnt_next + CNT_BHI, toB && hi, cap, G_KB_BHI);
             if (toA || toB) {
-                const NtQ qn = ntq(toA ? (Q.out_a + atA) : hi ? (Q.out[1] + atBh) : (Q.out[0] + atBl));
+                const NtQ qn = ntq(toA ? (QA_next + atA) : (QB_next + (hi ? cap - 1 - atBh : (long long)atBl)));
                 qn[A_IDX * cap] = pack2(tag, lm_hist);
 #pragma unroll
                 for (int k = 0; k < FSQ_NP; k++) { qn[(A_X + k) * cap] = xq[k]; qn[(A_DIAG + k) * cap] = q.dg[k]; }
@@ -1601,10 +1510,7 @@ static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 // FsqFitQueue (include/fsq.h) keeps an engine alive across batches, so that the long latency-bound tail of one batch
 // (a fit may need 200 sequential iterations) rides along in the full launches of the batches submitted after it.
 namespace {
-static_assert(FSQ_MAX_TICKETS <= CNT_LINE, "one line of done counters per stripe");
-enum { CTL_SLOW_TOTAL = 2 * CNT_SET, CTL_SLOW_CNT = 2 * CNT_SET + 1, CTL_F32_NEXT = 2 * CNT_SET + 2, CTL_ERR = 2 * CNT_SET + 3,
-       CTL_DONE = 2 * CNT_SET + CNT_LINE /* [NSTRIPE][CNT_LINE] */, CTL_INTS = CTL_DONE + NSTRIPE * CNT_LINE };
-static_assert(CTL_INTS * sizeof(int) <= 8192, "the control block is the first 8 KB of the workspace");
+enum { CTL_SLOW_TOTAL = 2 * CNT_SET, CTL_SLOW_CNT = 2 * CNT_SET + 1, CTL_F32_NEXT = 2 * CNT_SET + 2, CTL_ERR = 2 * CNT_SET + 3, CTL_DONE = 2 * CNT_SET + 8, CTL_INTS = CTL_DONE + FSQ_MAX_TICKETS };
 
 struct RoundsCfg {
     int lm_first = FSQ_LMPAR_FIRST, lm_lo = FSQ_LMPAR_LO, sync_mask = 3, force_slow_mod = 0, force_redo = 0, no_wave_prio = 0, trace = 0;
@@ -1674,11 +1580,9 @@ size_t cap_round(size_t q) { return (q + 255) & ~(size_t)255; }
 size_t layout_bytes(size_t pool, size_t qcap)
 {
     qcap = cap_round(qcap);
-    size_t b = 8192;
+    size_t b = 4096;
     b += al256(pool * 64) + al256(pool * FSQ_NPIX * 8) + al256(pool * sizeof(FitOut)) + al256(pool * sizeof(FitStat));
-    // queue A, B lo, B hi, C 1, C 3 in ping / pong copies (every list an array of its own: a striped list cannot share one
-    // with a list growing from the other end) + the slow queue
-    b += 2 * al256(qcap * A_LEN * 8) + 4 * al256(qcap * B_LEN * 8) + 4 * al256(qcap * C_LEN * 8) + al256(qcap * A_LEN * 8);
+    b += 2 * al256(qcap * A_LEN * 8) + 2 * al256(qcap * B_LEN * 8) + 2 * al256(qcap * C_LEN * 8) + al256(qcap * A_LEN * 8);
     return b;
 }
 }  // namespace
@@ -1687,7 +1591,7 @@ struct FsqFitQueue {
     Ctx c;
     size_t pool = 0, qcap = 0;
     int* ctl = nullptr;
-    double *QA[2], *QBlo[2], *QBhi[2], *QC1[2], *QC3[2], *SQ = nullptr;
+    double *QA[2], *QB[2], *QC[2], *SQ = nullptr;
     int *cset[2], *cSlow = nullptr;
     RoundsCfg cfg;
     bool ref = true, f32 = false, single_call = false;
@@ -1711,21 +1615,18 @@ struct FsqFitQueue {
         cfg = read_cfg();
         unsigned char* ws = (unsigned char*)d_ws;
         ctl = (int*)ws;     // two sets of queue counters (CNT_*), slow total, slow queue, done counters per ticket
-        size_t o = 8192;
+        size_t o = 4096;
         c.cap = (long long)qcap;
-        c.salt = 0;
         c.roi = (uint16_t*)(ws + o); o += al256(pool * 64);
         c.fvec = (double*)(ws + o); o += al256(pool * FSQ_NPIX * 8);
         c.out = (FitOut*)(ws + o); o += al256(pool * sizeof(FitOut));
         c.stat = (FitStat*)(ws + o); o += al256(pool * sizeof(FitStat));
         QA[0] = (double*)(ws + o); o += al256(qcap * A_LEN * 8);
         QA[1] = (double*)(ws + o); o += al256(qcap * A_LEN * 8);
-        for (int k = 0; k < 2; k++) {
-            QBlo[k] = (double*)(ws + o); o += al256(qcap * B_LEN * 8);
-            QBhi[k] = (double*)(ws + o); o += al256(qcap * B_LEN * 8);
-            QC1[k] = (double*)(ws + o); o += al256(qcap * C_LEN * 8);
-            QC3[k] = (double*)(ws + o); o += al256(qcap * C_LEN * 8);
-        }
+        QB[0] = (double*)(ws + o); o += al256(qcap * B_LEN * 8);
+        QB[1] = (double*)(ws + o); o += al256(qcap * B_LEN * 8);
+        QC[0] = (double*)(ws + o); o += al256(qcap * C_LEN * 8);
+        QC[1] = (double*)(ws + o); o += al256(qcap * C_LEN * 8);
         SQ = (double*)(ws + o); o += al256(qcap * A_LEN * 8);
         cset[0] = ctl; cset[1] = ctl + CNT_SET;
         cSlow = ctl + CTL_SLOW_CNT;
@@ -1778,7 +1679,7 @@ struct FsqFitQueue {
         } else if (f32) {
             // single precision: no rounds - the whole batch is fitted by one persistent launch (fsq_fit_f32.h), in stream order
             FSQ_HIP_CHECK(hipMemsetAsync(ctl + CTL_F32_NEXT, 0, sizeof(int), s));
-            hipLaunchKernelGGL(kinit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c, B.a, QA[0], cset[0]);
+            hipLaunchKernelGGL(kinit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c, B.a, QA[0], cset[0] + CNT_A);
             const long long waves = std::min<long long>((n + 63) / 64, (long long)cus * 12);          // 3 waves per SIMD (164 VGPRs)
             hipLaunchKernelGGL(kfit_f32, dim3((unsigned)waves), dim3(64), 0, s, c, B.a, ctl + CTL_F32_NEXT);
             hipLaunchKernelGGL(kfinish, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, c, B.a, rows);
@@ -1786,9 +1687,8 @@ struct FsqFitQueue {
             B.state = T_FINISHED;
         } else {
             const int cur = (int)(round & 1);
-            FSQ_HIP_CHECK(hipMemset2DAsync(c.done + t, CNT_LINE * sizeof(int), 0, sizeof(int), NSTRIPE, s));      // the ticket's counter of every stripe
-            c.salt = (unsigned)round * 2u + 1u;
-            hipLaunchKernelGGL(kinit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c, B.a, QA[cur], cset[cur]);
+            FSQ_HIP_CHECK(hipMemsetAsync(c.done + t, 0, sizeof(int), s));
+            hipLaunchKernelGGL(kinit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c, B.a, QA[cur], cset[cur] + CNT_A);
             B.state = T_FLIGHT;
             boundA += n; alive += n;
         }
@@ -1804,11 +1704,7 @@ struct FsqFitQueue {
         // dispatcher then balances the very uneven tile times, and small kernels of ANOTHER stream find free CU slots
         // between them.
         const int G = 64 / cfg.ka_lanes;
-        // A striped list's tiles are its stripes' chunks, enumerated by the kernels through a prefix sum over the stripes: the
-        // host's upper bound of the list's total / 64 + one partial chunk per stripe covers them whatever the balance.
-        auto chunks = [](long long n, int lists) { return (n + 63) / 64 + (long long)lists * NSTRIPE; };
-        const long long gA = boundA > 0 ? chunks(boundA, 1) * (64 / G) : 0;
-        c.salt = (unsigned)round * 2u;
+        const long long gA = (boundA + G - 1) / G;
         if (slow_pending > 0) {
             // fits that left the guarded operand ranges in EARLIER rounds: the plain-division build takes them from the slow
             // queue (whatever it holds by now - it may have grown since the host looked) and appends their queue-B records to
@@ -1816,30 +1712,26 @@ struct FsqFitQueue {
             // reserved a (dead) queue-B slot in this round, and worked off in the same round it would take a second one - the
             // step round's grid is sized for one slot per live fit, and tiles beyond it would never run (a lost fit, a batch
             // that never finishes; found by the round-3 fuzz on noise fields, where hundreds of fits take this path at once).
-            hipLaunchKernelGGL((kA_jacobian<false, 4>), dim3((unsigned)std::min<long long>((alive + 15) / 16, (long long)cus * 8)), dim3(64), 0, s, c, SQ, QBlo[cur], QBhi[cur], cset[cur], SQ, cSlow, cset[nxt]);
+            hipLaunchKernelGGL((kA_jacobian<false, 4>), dim3((unsigned)std::min<long long>((alive + 15) / 16, (long long)cus * 8)), dim3(64), 0, s, c, SQ, cSlow, QB[cur], cset[cur], SQ, cSlow, cset[nxt]);
             FSQ_HIP_CHECK(hipMemsetAsync(cSlow, 0, sizeof(int), s));
             slow_pending = 0;
         }
         if (gA > 0 && cfg.ka_lanes == 8)            // (kA also zeroes the counters of set nxt)
-            hipLaunchKernelGGL((kA_jacobian<true, 8>), dim3((unsigned)gA), dim3(64), cfg.ka_lds_pad, s, c, QA[cur], QBlo[cur], QBhi[cur], cset[cur], SQ, cSlow, cset[nxt]);
+            hipLaunchKernelGGL((kA_jacobian<true, 8>), dim3((unsigned)gA), dim3(64), cfg.ka_lds_pad, s, c, QA[cur], cset[cur] + CNT_A, QB[cur], cset[cur], SQ, cSlow, cset[nxt]);
         else if (gA > 0)
-            hipLaunchKernelGGL((kA_jacobian<true, 4>), dim3((unsigned)gA), dim3(64), cfg.ka_lds_pad, s, c, QA[cur], QBlo[cur], QBhi[cur], cset[cur], SQ, cSlow, cset[nxt]);
+            hipLaunchKernelGGL((kA_jacobian<true, 4>), dim3((unsigned)gA), dim3(64), cfg.ka_lds_pad, s, c, QA[cur], cset[cur] + CNT_A, QB[cur], cset[cur], SQ, cSlow, cset[nxt]);
         else
             FSQ_HIP_CHECK(hipMemsetAsync(cset[nxt], 0, CNT_SET * sizeof(int), s));
         // every fit in flight is in one of the four input lists of the step round by now (or terminated, or in the slow queue)
-        const long long gB = chunks(alive, 4);
+        const long long gB = (alive + 63) / 64 + 4;
         {
             // With few fits left a round is pure launch + wave latency: lmpar then runs to the end wherever a fit is met
             // (nothing is parked, no fit waits for the next round).
             const bool staged = alive > cfg.two_pass_min && cfg.lm_first < 10;
             KbLimits lims;
             lims.lim[0] = staged ? std::min(cfg.lm_lo, cfg.lm_first) : 10; lims.lim[1] = staged ? cfg.lm_first : 10; lims.lim[2] = staged ? cfg.lm_first : 10; lims.lim[3] = 10;
-            KbQueues Q;
-            Q.in[0] = QBlo[cur]; Q.in[1] = QBhi[cur]; Q.in[2] = QC1[cur]; Q.in[3] = QC3[cur];
-            Q.out[0] = QBlo[nxt]; Q.out[1] = QBhi[nxt]; Q.out[2] = QC1[nxt]; Q.out[3] = QC3[nxt]; Q.out_a = QA[nxt];
-            c.salt = (unsigned)round * 2u + 1u;
-            if (ref) hipLaunchKernelGGL((kB_step<true>), dim3((unsigned)gB), dim3(64), cfg.kb_lds_pad, s, c, Q, cset[cur], cset[nxt], lims);
-            else hipLaunchKernelGGL((kB_step<false>), dim3((unsigned)gB), dim3(64), 0, s, c, Q, cset[cur], cset[nxt], lims);
+            if (ref) hipLaunchKernelGGL((kB_step<true>), dim3((unsigned)gB), dim3(64), cfg.kb_lds_pad, s, c, QB[cur], QC[cur], cset[cur], QA[nxt], QB[nxt], QC[nxt], cset[nxt], lims);
+            else hipLaunchKernelGGL((kB_step<false>), dim3((unsigned)gB), dim3(64), 0, s, c, QB[cur], QC[cur], cset[cur], QA[nxt], QB[nxt], QC[nxt], cset[nxt], lims);
         }
         boundA = alive;                             // every fit of this round ends in a list of set nxt or is done
         round++;
@@ -1852,27 +1744,20 @@ struct FsqFitQueue {
         FSQ_HIP_CHECK(hipMemcpyAsync(h_ctl, ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, s));
         FSQ_HIP_CHECK(hipStreamSynchronize(s));
         const int cur = (int)(round & 1);
-        long long hc[CNT_C3 + 1] = {0, 0, 0, 0, 0};          // list totals: every stripe's count (a full stripe's tail keeps counting: clamp)
-        for (int k = 0; k < NSTRIPE; k++) {
-            const long long lim = (((long long)(qcap >> 6) - k + NSTRIPE - 1) / NSTRIPE) << 6;
-            for (int l = CNT_A; l <= CNT_C3; l++) hc[l] += std::min<long long>(h_ctl[CNT_SET * cur + k * CNT_LINE + l], lim);
-        }
+        const int* hc = h_ctl + CNT_SET * cur;
         boundA = hc[CNT_A];
         slow_pending = h_ctl[CTL_SLOW_CNT];
         alive = boundA + hc[CNT_BLO] + hc[CNT_BHI] + hc[CNT_C1] + hc[CNT_C3] + slow_pending;
         g_last_slow.store(h_ctl[CTL_SLOW_TOTAL]);
         if (h_ctl[CTL_ERR] != 0) {          // a kernel was about to write outside a queue / the pool (fsq_guard): an engine bug, say which
-            fprintf(stderr, "fsq: fit queue invariant %d broken (cap %lld, pool %lld, host bounds: A %lld alive %lld; counters A %lld B %lld+%lld C %lld+%lld slow %d)\n",
+            fprintf(stderr, "fsq: fit queue invariant %d broken (cap %lld, pool %lld, host bounds: A %lld alive %lld; counters A %d B %d+%d C %d+%d slow %d)\n",
                     h_ctl[CTL_ERR], (long long)qcap, (long long)pool, boundA, alive, hc[CNT_A], hc[CNT_BLO], hc[CNT_BHI], hc[CNT_C1], hc[CNT_C3], h_ctl[CTL_SLOW_CNT]);
             return FSQ_EINTERNAL;
         }
-        if (cfg.trace) fprintf(stderr, "round %lld: A=%lld B=%lld+%lld C=%lld+%lld slow=%lld total_slow=%d\n", round - 1, boundA, hc[CNT_BLO], hc[CNT_BHI], hc[CNT_C1], hc[CNT_C3], slow_pending, h_ctl[CTL_SLOW_TOTAL]);
+        if (cfg.trace) fprintf(stderr, "round %lld: A=%lld B=%d+%d C=%d+%d slow=%lld total_slow=%d\n", round - 1, boundA, hc[CNT_BLO], hc[CNT_BHI], hc[CNT_C1], hc[CNT_C3], slow_pending, h_ctl[CTL_SLOW_TOTAL]);
         int fin = 0;
         for (auto& t : b) {
-            if (t.state != T_FLIGHT) continue;
-            long long done = 0;
-            for (int k = 0; k < NSTRIPE; k++) done += h_ctl[CTL_DONE + k * CNT_LINE + t.a.ticket];
-            if (done < t.a.n) continue;
+            if (t.state != T_FLIGHT || h_ctl[CTL_DONE + t.a.ticket] < t.a.n) continue;
             // (s_finish: a stand-alone call hands its rows over on the caller's stream, idle and ordered here)
             hipLaunchKernelGGL(kfinish, dim3((unsigned)((t.a.n + 63) / 64)), dim3(64), 0, s_finish, c, t.a, t.rows);
             if (t.ev) FSQ_HIP_CHECK(hipEventRecord(t.ev, s_finish));

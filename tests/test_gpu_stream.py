@@ -202,9 +202,7 @@ def test_fit_queue_filled_exactly_to_its_capacity(env, monkeypatch, force_slow):
     """A queue of 256 positions holding exactly 256 live fits, submitted as 100 + 156 (neither a multiple of 64): every list
     becomes exactly full - in round 1 every fit sits in B lo - and the lanes that append nothing must not trip the capacity
     guard (they were handed the counter value behind the wave's reservation, == cap, and reported FSQ_EINTERNAL).
-    With striped lists (round 4) only four of the sixteen stripes own a chunk of such a small queue: all the others turn their
-    appends away and the overflow into the following stripes is what places every fit.  force_slow: every fit through the
-    plain-division kernel in every round (its appends go through the same reservation)."""
+    force_slow: every fit through the plain-division kernel in every round (its appends go through the same reservation)."""
     torch, N, E, pflib, synth = env
     if force_slow:
         monkeypatch.setenv("FSQ_DEBUG_FORCE_SLOW", "1")
