@@ -1,5 +1,5 @@
 """Host worker process of the file layer (pflib.image_batch): reads pickled requests (function name, arguments) from stdin,
-runs pflib._read_job / pflib._save_job and writes the pickled result to stdout.  Started as
+runs pflib._read_job / pflib._save_records_job (/ _save_job) and writes the pickled result to stdout.  Started as
 `python -m fluorosequencingimageanalysis_amd._io_worker` by pflib._IoPool - a plain child process with its own interpreter,
 independent of what the parent's __main__ is (multiprocessing's spawn would re-import it) and of the GPU state of the parent
 (nothing here touches the GPU)."""
@@ -12,7 +12,7 @@ def main():
     import logging
     logging.getLogger().addHandler(logging.NullHandler())      # failures travel back to the parent, which logs them
     from . import pflib
-    jobs = {"read": pflib._read_job, "save": pflib._save_job}
+    jobs = {"read": pflib._read_job, "save": pflib._save_job, "save_records": pflib._save_records_job}
     inp, out = sys.stdin.buffer, sys.stdout.buffer
     sys.stdout = sys.stderr                     # stray prints must not corrupt the reply stream
     while True:

@@ -1,13 +1,21 @@
 // fsq_consolidate.hip - K5: R^2 filter, consolidation of competing PSFs and re-keying, per field.
 // Reference: pflib.find_peptides, pflib.py:466 (filter), 477-512 (consolidation), 514-519 (re-key).
 //
-// The reference's loops are sequential and order dependent (raster order of the candidate pixels,
-// raster order inside each search window).  One 64-lane wave owns one field and walks the surviving
-// candidates in that order; the window scan of one candidate (up to (2r+5)^2 cells) is done by the
-// lanes in parallel and resolved with ballots so that the outcome equals the sequential scan:
-//   rivals are visited in raster order; every rival with a smaller R^2 is deleted until the first
-//   rival whose R^2 is not smaller - then the candidate itself is deleted and the scan stops.
-// A pixel->row grid (int32 per pixel, workspace) plays the role of the reference's dict.
+// The reference's loops are sequential and order dependent (raster order of the candidate pixels, raster order inside each
+// search window): a candidate that still has its dict entry scans the (2r+5)^2 window around it, deleting every rival
+// with a smaller R^2 until the first rival whose R^2 is not smaller - then the candidate itself is deleted and the scan
+// stops.  What one candidate's turn reads and writes lies inside its own window, so two candidates whose windows do not
+// overlap - more than 2 (r + 2) pixels apart in h or in w - commute, and the sequential result is reproduced exactly by
+// ANY schedule in which a candidate takes its turn after every raster-earlier candidate whose window overlaps its own.
+// Round 4: one BLOCK of 8 or 16 waves owns a field.  Wave v takes the surviving candidates v, v + NW, ... in raster order;
+// before a candidate's turn the wave looks at the raster-earlier half of the (4r+9)^2 neighbourhood and waits until no
+// entry alive there that has not had its turn (a flag per candidate) can still touch this candidate's window - it lies in
+// the window itself or shares a living entry with it; the turn itself - the window scan, done by the lanes in parallel
+// and resolved with ballots so that it equals the reference's sequential scan - is the round-1 code.  The candidate with
+// the smallest number that has not had its turn never waits, so the scheme cannot deadlock.  (Round 3 walked a field with
+// ONE wave: 21-30 ms for a 2 048^2 field of 46 000 candidates whatever the number of fields.)
+// A pixel -> candidate grid (int32 per pixel, workspace) plays the role of the reference's dict: -1 empty, i >= 0 the
+// entry of candidate i, -(i + 2) the deleted entry of candidate i.
 #include "fsq_common.h"
 #include "fsq_devmath.h"
 
@@ -15,136 +23,282 @@ namespace {
 
 __device__ __forceinline__ double round_key(double x, int py2) { return py2 ? round(x) : rint(x); }
 
-// grid = n_fields blocks of 64 threads (one wave per field)
-__global__ void __launch_bounds__(64) k5_consolidate(FsqRow* __restrict__ rows, const int* __restrict__ counts,
-                                                     const int* __restrict__ offsets, int H, int W, double r2_thr,
-                                                     int radius, int py2, int* __restrict__ grid_all,
-                                                     int* __restrict__ keep, int* __restrict__ nkeep)
+// loads / stores other waves of the block act upon while this one runs: atomic at WORKGROUP scope - all waves of a block sit on
+// one CU and share its vector L1, so nothing has to leave the CU (agent-scope fences write back and invalidate the whole L2
+// of the XCD on gfx950: tried first, 50 ms per launch)
+__device__ __forceinline__ int ld_shared_i(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void st_shared_i(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int ld_shared_b(const unsigned char* p) { return (int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane)
 {
-    const int f = blockIdx.x, lane = threadIdx.x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(v, d); v += (lane >= d) ? t : 0; }
+    return v;
+}
+
+// Ordered compaction over the candidates 0 .. cnt-1 of a field by all waves of the block: out[out_base + rank(i)] = value(i) for
+// every i with pred(i), ranks in index order.  chunkc: cnt / 64 + 1 ints of scratch.  Returns the number selected.
+template <typename Pred, typename Val>
+__device__ int block_compact(int cnt, int* chunkc, int* out, int out_base, Pred pred, Val value, int* s_total)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
+    const int nchunk = (cnt + 63) >> 6;
+    for (int c = wave; c < nchunk; c += NW) {
+        const int i = c * 64 + lane;
+        const unsigned long long m = __ballot(i < cnt && pred(i));
+        if (lane == 0) chunkc[c] = __popcll(m);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        int run = 0;
+        for (int base = 0; base < nchunk; base += 64) {
+            const int c = base + lane;
+            const int v = c < nchunk ? chunkc[c] : 0;
+            const int incl = wave_incl_scan(v, lane);
+            if (c < nchunk) chunkc[c] = run + incl - v;
+            run += __shfl(incl, 63);
+        }
+        if (lane == 0) *s_total = run;
+    }
+    __syncthreads();
+    for (int c = wave; c < nchunk; c += NW) {
+        const int i = c * 64 + lane;
+        const bool ok = i < cnt && pred(i);
+        const unsigned long long m = __ballot(ok);
+        if (ok) out[out_base + chunkc[c] + __popcll(m & ((1ull << lane) - 1ull))] = value(i);
+    }
+    __syncthreads();
+    return *s_total;
+}
+
+// grid = n_fields blocks of NW waves (one block per field)
+__global__ void __launch_bounds__(1024) k5_consolidate(FsqRow* __restrict__ rows, const int* __restrict__ counts,
+                                                       const int* __restrict__ offsets, int H, int W, double r2_thr,
+                                                       int radius, int py2, int* __restrict__ grid_all,
+                                                       unsigned char* __restrict__ turn_all, int* __restrict__ chunk_all, long long chunk_stride,
+                                                       int* __restrict__ keep, int* __restrict__ nkeep)
+{
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
     const int off = offsets[f], cnt = counts[f];
     int* grid = grid_all + (size_t)f * H * W;          // pre-set to -1
+    unsigned char* turn = turn_all + (size_t)f * H * W; // by candidate: 1 once the candidate has had its turn
+    int* chunkc = chunk_all + (size_t)f * chunk_stride;
     FsqRow* R = rows + off;
     const double rr = (double)(radius * radius);
+    __shared__ int s_total, s_assert;
 
-    // dict insertion (setdefault, pflib.py:477): survivors of the R^2 filter (NaN passes, :466).  Their indices are
-    // also compacted, in order, into this field's slice of `keep` (scratch until the final list is written): the two
-    // sequential walks below then touch ~15 % of the candidates and read each survivor's row ONCE, 64 rows at a time,
-    // instead of chasing two dependent global loads per candidate.
+    // dict insertion (setdefault, pflib.py:477): survivors of the R^2 filter (NaN passes, :466).  Their indices are also
+    // compacted, in order, into this field's slice of `keep` (scratch until the final list is written): the walks below
+    // then touch ~15 % of the candidates.
     int* surv = keep + off;
-    int nsurv = 0;
-    for (int base = 0; base < cnt; base += 64) {
-        const int i = base + lane;
-        bool ok = false;
-        if (i < cnt) {
-            R[i].key_h = -1; R[i].key_w = -1;
-            ok = !(R[i].r2 < r2_thr);
-            if (ok) grid[(size_t)R[i].h * W + R[i].w] = i;
-        }
-        const unsigned long long m = __ballot(ok);
-        if (ok) surv[nsurv + __popcll(m & ((1ull << lane) - 1ull))] = i;
-        nsurv += __popcll(m);
+    for (int i = tid; i < cnt; i += blockDim.x) {
+        R[i].key_h = -1; R[i].key_w = -1;
+        if (!(R[i].r2 < r2_thr)) { grid[(size_t)R[i].h * W + R[i].w] = i; turn[i] = 0; }
     }
+    __syncthreads();
+    const int nsurv = block_compact(cnt, chunkc, keep, off, [&](int i) { return !(R[i].r2 < r2_thr); }, [](int i) { return i; }, &s_total);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __syncthreads();
 
     // consolidation, pflib.py:479-512
-    for (int sbase = 0; sbase < nsurv; sbase += 64) {
-        const int nb = min(64, nsurv - sbase);
-        int my_i = -1, my_h = 0, my_w = 0;
-        double my_h0 = 0., my_w0 = 0., my_r2 = 0.;
-        if (lane < nb) {
-            my_i = surv[sbase + lane];
-            my_h = R[my_i].h; my_w = R[my_i].w; my_h0 = R[my_i].h0; my_w0 = R[my_i].w0; my_r2 = R[my_i].r2;
-        }
-        for (int j = 0; j < nb; j++) {
-            const int i = __shfl(my_i, j), h = __shfl(my_h, j), w = __shfl(my_w, j);
-            if (grid[(size_t)h * W + w] != i) continue;        // already deleted by an earlier candidate (wave-uniform)
-            const double h0 = __shfl(my_h0, j), w0 = __shfl(my_w0, j), r2i = __shfl(my_r2, j);
-            const int h_lo = max(0, h - radius - 2), h_hi = min(h + radius + 3, H);
-            const int w_lo = max(0, w - radius - 2), w_hi = min(w + radius + 3, W);
-            const int ww = w_hi - w_lo, ncell = (h_hi - h_lo) * ww;
-            bool dead = false;
-            for (int base = 0; base < ncell && !dead; base += 64) {
-                int c = base + lane;
-                bool rival = false, lose = false;
-                size_t cell = 0;
-                if (c < ncell) {
-                    int hd = h_lo + c / ww, wd = w_lo + c % ww;
-                    cell = (size_t)hd * W + wd;
-                    int k = grid[cell];
-                    if (k >= 0 && !(hd == h && wd == w)) {
-                        double dh = h0 - R[k].h0, dw = w0 - R[k].w0;
-                        if (!(fsq_pow2(dh) + fsq_pow2(dw) > rr)) {       // numpy scalar **2, pflib.py:505
-                            rival = true;
-                            lose = !(r2i > R[k].r2);                    // pflib.py:508
-                        }
+    const int D = 2 * (radius + 2);                     // windows overlap up to this distance
+    // Which wave takes which survivor: wave v owns the v-th vertical STRIP of the field and walks the survivors of its strip
+    // in raster order.  (Dealing the survivors out in turn - wave v takes survivor v, v + NW, ... - makes neighbours in
+    // raster order, which are neighbours in the image, wait for each other all the time: measured, 3 of 8 waves busy.)
+    // With strips, only the candidates within 2 (r + 2) pixels of a strip border depend on another wave at all, and that
+    // wave has usually passed the row in question.  Every wave reads the whole survivor list, 64 entries at a time.
+    const int strip_w = (W + NW - 1) / NW;
+    for (int cbase = 0; cbase < nsurv; cbase += 64) {
+      int c_i = -1, c_h = 0, c_w = 0;
+      double c_h0 = 0., c_w0 = 0., c_r2 = 0.;
+      if (cbase + lane < nsurv) {
+          c_i = surv[cbase + lane];
+          c_h = R[c_i].h; c_w = R[c_i].w; c_h0 = R[c_i].h0; c_w0 = R[c_i].w0; c_r2 = R[c_i].r2;
+      }
+#ifdef FSQ_EXPERIMENT_NO_TURNS              // timing experiment (results wrong): the kernel without the consolidation turns
+      unsigned long long mine = 0ull;
+#else
+      unsigned long long mine = __ballot(c_i >= 0 && (c_w / strip_w) == wave);
+#endif
+      while (mine) {
+        const int src = __ffsll((long long)mine) - 1;
+        mine &= mine - 1;
+        const int i = __shfl(c_i, src), h = __shfl(c_h, src), w = __shfl(c_w, src);
+        const double h0 = __shfl(c_h0, src), w0 = __shfl(c_w0, src), r2i = __shfl(c_r2, src);
+        // The turn: (a) wait for the raster-earlier entries that can still change what this turn sees, (b) the window scan.
+        // An earlier entry j that has not had its turn can only touch this candidate's window if it lies in it itself, or
+        // if some living entry lies in BOTH windows (j's turn deletes j itself or rivals inside j's window; entries never
+        // appear during consolidation) - the same holds the other way round for the later entries, so whatever this turn
+        // reads is final once no such j is left.  Everything is loaded NG x 64 cells at a time with all loads of a group in
+        // flight together: a turn is a handful of dependent memory round trips and nothing else.
+        constexpr int NG = 5, NGW = 3;      // (defaults: 312 raster-earlier cells of the 25 x 25 neighbourhood, 13 x 13 window)
+        const int rw = radius + 2;
+        const int h_lo = max(0, h - rw), h_hi = min(h + rw + 1, H), w_lo = max(0, w - rw), w_hi = min(w + rw + 1, W);
+        const int ww = w_hi - w_lo, ncell = (h_hi - h_lo) * ww;
+        const bool small_window = ncell <= 64 * NGW;               // (radius <= 4: the window fits the registers of one pass)
+        const int nh_lo = max(0, h - D), nw_lo = max(0, w - D), nw_hi = min(W, w + D + 1);
+        const int nww = nw_hi - nw_lo, nearly = (h - nh_lo) * nww + (w - nw_lo);
+        int wk[NGW];                        // the window's cells (small windows), as loaded by the last look
+        bool wk_valid = false;
+        while (true) {
+            // (1) the raster-earlier entries of the neighbourhood that are alive and have not had their turn: their pixels
+            // are noted (lane q keeps the q-th one); (2) only THEN the window is read - an entry that finished its turn before
+            // (1) has left its mark in what (2) sees, one that is noted in (1) is judged against what (2) sees: whatever it
+            // still shares with this window is alive there
+            int pend_h = 0, pend_w = 0, npend = 0;
+            for (int base = 0; base < nearly; base += 64 * NG) {
+                int kk[NG], tt[NG];
+#pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    const int c = base + 64 * g + lane;
+                    kk[g] = (c < nearly) ? ld_shared_i(&grid[(size_t)(nh_lo + c / nww) * W + (nw_lo + c % nww)]) : -1;
+                }
+#pragma unroll
+                for (int g = 0; g < NG; g++) tt[g] = (kk[g] >= 0) ? ld_shared_b(&turn[kk[g]]) : 1;
+#pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    unsigned long long m = __ballot(tt[g] == 0);
+                    while (m) {
+                        const int c = base + 64 * g + (__ffsll((long long)m) - 1);
+                        m &= m - 1;
+                        if (lane == (npend & 63)) { pend_h = nh_lo + c / nww; pend_w = nw_lo + c % nww; }
+                        npend++;
                     }
                 }
-                unsigned long long mlose = __ballot(lose);
-                int first = mlose ? (__ffsll((long long)mlose) - 1) : 64;
-                if (rival && lane < first) grid[cell] = -1;             // rivals with smaller R^2 die
-                if (mlose) {
-                    if (lane == 0) grid[(size_t)h * W + w] = -1;        // the candidate itself dies, scan stops
-                    dead = true;
+            }
+            wk_valid = false;
+#ifdef FSQ_EXPERIMENT_NO_WAIT               // timing experiment (results wrong): nobody waits for anybody
+            npend = 0;
+#endif
+            if (npend == 0) break;
+            bool blocked = !small_window || npend > 64;
+            if (!blocked) {
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#pragma unroll
+                for (int g = 0; g < NGW; g++) {
+                    const int c = 64 * g + lane;
+                    wk[g] = -1;
+                    if (c < ncell) {
+                        const int hd = h_lo + c / ww, wd = w_lo + c % ww;
+                        if (!(hd == h && wd == w)) wk[g] = ld_shared_i(&grid[(size_t)hd * W + wd]);
+                    }
                 }
-                __syncthreads();
+                wk_valid = true;
+                for (int q = 0; q < npend && !blocked; q++) {
+                    const int hj = __shfl(pend_h, q), wj = __shfl(pend_w, q);
+                    if (abs(hj - h) <= rw && abs(wj - w) <= rw) blocked = true;        // it lies in this window itself
+                    else {
+                        bool both = false;
+#pragma unroll
+                        for (int g2 = 0; g2 < NGW; g2++) {
+                            const int c2 = 64 * g2 + lane;
+                            both = both || (wk[g2] >= 0 && abs(h_lo + c2 / ww - hj) <= rw && abs(w_lo + c2 % ww - wj) <= rw);
+                        }
+                        if (__ballot(both)) blocked = true;                             // a living entry lies in both windows
+                    }
+                }
+            }
+            if (!blocked) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        {
+            const int own = ld_shared_i(&grid[(size_t)h * W + w]);     // (issued together with the window's first cells)
+            bool dead = false;
+            for (int base = 0; base < ncell && !dead; base += 64 * NGW) {
+                int kk[NGW];
+                double rh0[NGW], rw0[NGW], rr2[NGW];
+#pragma unroll
+                for (int g = 0; g < NGW; g++) {
+                    const int c = base + 64 * g + lane;
+                    kk[g] = -1;
+                    if (wk_valid) kk[g] = wk[g];
+                    else if (c < ncell) {
+                        const int hd = h_lo + c / ww, wd = w_lo + c % ww;
+                        if (!(hd == h && wd == w)) kk[g] = ld_shared_i(&grid[(size_t)hd * W + wd]);
+                    }
+                }
+                if (own != i) break;                                    // deleted by an earlier candidate: nothing to do
+#pragma unroll
+                for (int g = 0; g < NGW; g++) {
+                    const int k = kk[g] >= 0 ? kk[g] : i;
+                    rh0[g] = R[k].h0; rw0[g] = R[k].w0; rr2[g] = R[k].r2;
+                }
+#pragma unroll
+                for (int g = 0; g < NGW; g++) {
+                    if (dead || base + 64 * g >= ncell) continue;       // (wave-uniform)
+                    const int c = base + 64 * g + lane;
+                    bool rival = false, lose = false;
+                    if (kk[g] >= 0) {
+                        const double dh = h0 - rh0[g], dw = w0 - rw0[g];
+                        if (!(fsq_pow2(dh) + fsq_pow2(dw) > rr)) {       // numpy scalar **2, pflib.py:505
+                            rival = true;
+                            lose = !(r2i > rr2[g]);                     // pflib.py:508
+                        }
+                    }
+                    const unsigned long long mlose = __ballot(lose);
+                    const int first = mlose ? (__ffsll((long long)mlose) - 1) : 64;
+                    if (rival && lane < first) st_shared_i(&grid[(size_t)(h_lo + c / ww) * W + (w_lo + c % ww)], -(kk[g] + 2));     // rivals with smaller R^2 die
+                    if (mlose) {
+                        if (lane == 0) st_shared_i(&grid[(size_t)h * W + w], -(i + 2));     // the candidate itself dies, scan stops
+                        dead = true;
+                    }
+                }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                                // the turn's deletions are visible before the flag is
+        if (lane == 0) __hip_atomic_store(&turn[i], (unsigned char)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
     }
-
-    // re-key, pflib.py:514-519.  Whether an entry is still alive cannot change during this loop (entries only ever
-    // move into EMPTY cells), so liveness, the rounded key and the key write are done 64 survivors at a time; only
-    // the entries whose key actually moves are then replayed one by one in index order, because the reference's
-    // assert looks at the dict as it is at that moment.
-    __shared__ int s_assert;
-    if (lane == 0) s_assert = 0;
+    if (tid == 0) s_assert = 0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __syncthreads();
-    for (int sbase = 0; sbase < nsurv; sbase += 64) {
-        const int s_ = sbase + lane;
-        bool moved = false;
-        int i = -1, hr = 0, wr = 0;
-        size_t g = 0;
-        if (s_ < nsurv) {
-            i = surv[s_];
-            g = (size_t)R[i].h * W + R[i].w;
-            if (grid[g] == i) {
-                hr = (int)round_key(R[i].h0, py2); wr = (int)round_key(R[i].w0, py2);
-                R[i].key_h = hr; R[i].key_w = wr;
-                moved = (hr != R[i].h) || (wr != R[i].w);
+
+    // re-key, pflib.py:514-519: every entry still alive whose rounded centre differs from its pixel moves to the rounded
+    // key, in index order, and the reference asserts that the new key is free AT THAT MOMENT.  No assertion fires iff
+    // (1) a moving entry's target holds, at the start, nothing or an entry that itself moves away EARLIER (smaller index) and
+    // (2) no two moving entries have the same target; if one fires the field has no table at all (nkeep = -1), so only
+    // whether one fires is reproduced - by all threads at once: check (1) on the untouched grid, vacate, land with an
+    // exchange that reports a second arrival.
+    auto key_of = [&](int i, int* hr, int* wr) { *hr = (int)round_key(R[i].h0, py2); *wr = (int)round_key(R[i].w0, py2); };
+    for (int s_ = tid; s_ < nsurv; s_ += blockDim.x) {
+        const int i = surv[s_];
+        if (grid[(size_t)R[i].h * W + R[i].w] != i) continue;
+        int hr, wr;
+        key_of(i, &hr, &wr);
+        R[i].key_h = hr; R[i].key_w = wr;
+        if ((hr != R[i].h || wr != R[i].w) && hr >= 0 && hr < H && wr >= 0 && wr < W) {
+            const int j = grid[(size_t)hr * W + wr];
+            if (j >= 0) {
+                int hj, wj;
+                key_of(j, &hj, &wj);
+                if (!(j < i && (hj != R[j].h || wj != R[j].w))) s_assert = 1;
             }
-        }
-        unsigned long long mm = __ballot(moved);
-        while (mm) {
-            const int b = __ffsll((long long)mm) - 1;
-            mm &= mm - 1;
-            if (lane == b) {
-                grid[g] = -1;
-                if (hr >= 0 && hr < H && wr >= 0 && wr < W) {
-                    size_t g2 = (size_t)hr * W + wr;
-                    if (grid[g2] >= 0) s_assert = 1;                 // assert (h_0_r, w_0_r) not in pixel_bins
-                    else grid[g2] = i;
-                }
-            }
-            __syncthreads();
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
+    for (int s_ = tid; s_ < nsurv; s_ += blockDim.x) {
+        const int i = surv[s_];
+        if (R[i].key_h >= 0 && (R[i].key_h != R[i].h || R[i].key_w != R[i].w)) grid[(size_t)R[i].h * W + R[i].w] = -1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
+    for (int s_ = tid; s_ < nsurv; s_ += blockDim.x) {
+        const int i = surv[s_], hr = R[i].key_h, wr = R[i].key_w;
+        if (hr >= 0 && (hr != R[i].h || wr != R[i].w) && hr < H && wr >= 0 && wr < W)
+            if (atomicExch(&grid[(size_t)hr * W + wr], i) >= 0) s_assert = 1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __syncthreads();
 
     // kept list in the reference's dict order: untouched keys in insertion order, re-keyed ones appended
-    int nk = 0;
-    for (int pass = 0; pass < 2; pass++)
-        for (int base = 0; base < cnt; base += 64) {
-            int i = base + lane;
-            bool sel = false;
-            if (i < cnt && R[i].key_h >= 0) {
-                bool moved = (R[i].key_h != R[i].h) || (R[i].key_w != R[i].w);
-                sel = (pass == 0) ? !moved : moved;
-            }
-            unsigned long long m = __ballot(sel);
-            if (sel) keep[off + nk + __popcll(m & ((1ull << lane) - 1ull))] = off + i;
-            nk += __popcll(m);
-        }
-    if (lane == 0) nkeep[f] = s_assert ? -1 : nk;
+    const int nk0 = block_compact(cnt, chunkc, keep, off, [&](int i) { return R[i].key_h >= 0 && R[i].key_h == R[i].h && R[i].key_w == R[i].w; },
+                                  [&](int i) { return off + i; }, &s_total);
+    const int nk1 = block_compact(cnt, chunkc, keep, off + nk0, [&](int i) { return R[i].key_h >= 0 && (R[i].key_h != R[i].h || R[i].key_w != R[i].w); },
+                                  [&](int i) { return off + i; }, &s_total);
+    if (tid == 0) nkeep[f] = s_assert ? -1 : nk0 + nk1;
 }
 
 __global__ void k5_total(int* __restrict__ nkeep, int n_fields)
@@ -197,10 +351,13 @@ extern "C" int fsq_kept_rows(const FsqRow* d_rows, const int32_t* d_keep, const 
     return FSQ_OK;
 }
 
+// per field: the pixel -> candidate grid (int32 per pixel), a turn flag per candidate (at most one candidate per pixel) and
+// the chunk counters of the ordered compactions (one per 64 candidates)
+static int64_t k5_chunk_stride(int H, int W) { return ((int64_t)H * W + 63) / 64 + 2; }
 extern "C" int64_t fsq_consolidate_workspace_bytes(int n_fields, int H, int W)
 {
     if (n_fields < 1 || H < 1 || W < 1) return FSQ_EINVAL;
-    return (int64_t)n_fields * H * W * 4;
+    return (int64_t)n_fields * ((int64_t)H * W * 5 + k5_chunk_stride(H, W) * 4) + 256;
 }
 
 extern "C" int fsq_consolidate(FsqRow* d_rows, const int32_t* d_counts, const int32_t* d_offsets, int n_fields, int H,
@@ -209,11 +366,17 @@ extern "C" int fsq_consolidate(FsqRow* d_rows, const int32_t* d_counts, const in
 {
     if (radius < 2) return FSQ_EINVAL;                                // pflib.py:431-432 -> ValueError
     if (n_fields < 1 || H < 5 || W < 5 || !d_rows || !d_counts || !d_offsets || !d_keep || !d_nkeep || !d_workspace) return FSQ_EINVAL;
-    if (workspace_bytes < (int64_t)n_fields * H * W * 4) return FSQ_ENOMEM;
+    if (workspace_bytes < fsq_consolidate_workspace_bytes(n_fields, H, W)) return FSQ_ENOMEM;
     hipStream_t s = (hipStream_t)stream;
-    FSQ_HIP_CHECK(hipMemsetAsync(d_workspace, 0xFF, (size_t)n_fields * H * W * 4, s));
-    hipLaunchKernelGGL(k5_consolidate, dim3(n_fields), dim3(64), 0, s, d_rows, d_counts, d_offsets, H, W, r2_threshold,
-                       radius, py2_round, (int*)d_workspace, d_keep, d_nkeep);
+    const size_t px = (size_t)n_fields * H * W;
+    int* grid = (int*)d_workspace;
+    unsigned char* turn = (unsigned char*)d_workspace + px * 4;
+    int* chunks = (int*)((unsigned char*)d_workspace + ((px * 5 + 255) & ~(size_t)255));
+    FSQ_HIP_CHECK(hipMemsetAsync(d_workspace, 0xFF, px * 4, s));
+    // 16 waves per field for large fields (thousands of survivors to take turns), 8 otherwise
+    const int threads = ((int64_t)H * W > (1 << 20)) ? 1024 : 512;
+    hipLaunchKernelGGL(k5_consolidate, dim3(n_fields), dim3(threads), 0, s, d_rows, d_counts, d_offsets, H, W, r2_threshold,
+                       radius, py2_round, grid, turn, chunks, (long long)k5_chunk_stride(H, W), d_keep, d_nkeep);
     hipLaunchKernelGGL(k5_total, dim3(1), dim3(1), 0, s, d_nkeep, n_fields);
     FSQ_HIP_CHECK(hipGetLastError());
     return FSQ_OK;

@@ -626,6 +626,9 @@ def find_peptides_records(images, median_filter_size=5, correlation_matrix=defau
     mode = _solver_mode(solver)
     if consolidation_radius < 2:
         raise ValueError("consolidation_radius must be at least 2")
+    if unused.get("fit_type", "gauss") != 'gauss':
+        raise NotImplementedError("fit_type='monte_carlo' draws from an unseeded RNG in the reference "
+                                  "(pflib.py:117-177) and is not reproduced")
     imgs, fmt = _engine.as_pixel_fields(images)
     prm = _engine.detect_params(median_filter_size, correlation_matrix, c_std, fmt)
     if imgs.ndim != 3:
@@ -912,7 +915,7 @@ WINDOW_PIXELS = 8 * CHUNK_PIXELS
 # (multiprocessing.Pool, pflib.py:1082-1099); here the GPU work stays in this process and the workers do the file work:
 # read_image before, save_psfs_* after.  They are spawned (never forked: this process may have initialised the GPU) and
 # import nothing that touches the GPU.
-IO_WORKERS = None               # None: min(12, half the cores); 0: everything in this process
+IO_WORKERS = None               # None: the cores this process may run on less two, at most 16; 0: everything in this process
 _IO_POOL = {"pool": None, "n": 0}
 IO_POOL_MIN_IMAGES = 16         # lists shorter than this are not worth starting the workers for
 
@@ -972,7 +975,11 @@ class _IoPool:
 
 
 def _io_pool(n_images, num_processes=None):
-    n = IO_WORKERS if IO_WORKERS is not None else min(12, max(1, (os.cpu_count() or 2) // 2))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 2
+    n = IO_WORKERS if IO_WORKERS is not None else min(16, max(1, cores - 2))      # (the cores this process may use, less the GPU's driver threads)
     if num_processes is not None:
         n = int(num_processes)
     if n <= 0 or n_images < IO_POOL_MIN_IMAGES:
@@ -1023,6 +1030,21 @@ def _save_job(psfs, converted, timestamp_epoch):
         return (save_psfs_pkl(psfs, image_path=converted, timestamp_epoch=timestamp_epoch),
                 save_psfs_csv(psfs, image_path=converted, timestamp_epoch=timestamp_epoch),
                 save_psfs_png(psfs, image_path=converted, timestamp_epoch=timestamp_epoch)), None
+    except Exception as e:      # noqa: BLE001
+        return None, _portable_error(e)
+
+
+def _save_records_job(blob, pixel_format, converted, timestamp_epoch):
+    """(worker process or inline) The peak records of ONE image (bytes of uint8[k, engine.PEAK_RECORD_BYTES], as the GPU wrote
+    them) -> the reference's dict (built HERE, not in the process that drives the GPU) -> pickle and CSV, then the PNG overlay
+    last, so that a reader of the pickles never waits for the cosmetics.  -> ((pkl, csv, png) paths, None) or (None, exception)."""
+    try:
+        rec = np.frombuffer(blob, dtype=np.uint8).reshape(-1, _engine.PEAK_RECORD_BYTES)
+        psfs = records_to_dicts(rec, [len(rec)], pixel_format)[0]
+        pkl = save_psfs_pkl(psfs, image_path=converted, timestamp_epoch=timestamp_epoch)
+        tab = save_psfs_csv(psfs, image_path=converted, timestamp_epoch=timestamp_epoch)
+        png = save_psfs_png(psfs, image_path=converted, timestamp_epoch=timestamp_epoch)
+        return (pkl, tab, png), None
     except Exception as e:      # noqa: BLE001
         return None, _portable_error(e)
 
@@ -1140,24 +1162,47 @@ def image_batch(image_paths, find_peptides_parameters=None, timestamp_epoch=None
             else:
                 done.setdefault(ap, (converted,) + tuple(files))
 
+    # The process that drives the GPU never creates a Python object per peak: a window's images go through the continuous-
+    # batching pipeline as one stack and come back as ONE byte table (378 bytes per peak, find_peptides_records); every
+    # image's slice of it travels to a host worker as bytes, and the worker builds the reference's dict and writes the files
+    # (round 3 built the dicts here and pickled every one of them into a worker's pipe: 57 images/s).
     for shape, members in _windows(paths, unreadable, pool):
+        err, rec, counts, fmt = None, None, None, N.PIXELS_U16
         try:
-            res = find_peptides_batch(np.stack([a for _, _, a in members]), errors='return', **find_peptides_parameters)
+            _check_find_peptides_parameters(find_peptides_parameters)
+            rec, counts, fmt = find_peptides_records(np.stack([a for _, _, a in members]), **find_peptides_parameters)
+            offs = np.concatenate([[0], np.cumsum(np.maximum(counts, 0))])
         except Exception as e:      # noqa: BLE001 - parameter errors etc. hit every image of the window
-            res = [e] * len(members)
-        for (ap, converted, _), psfs in zip(members, res):
-            if isinstance(psfs, Exception):
-                log.error("find_peptides failed for %s", ap, exc_info=(type(psfs), psfs, psfs.__traceback__))
+            err = e
+        for m, (ap, converted, _) in enumerate(members):
+            e = err
+            if e is None and counts[m] < 0:
+                e = AssertionError("field %d: re-keyed peak collides with an existing key (pflib.py:518)" % m)
+            if e is not None:
+                log.error("find_peptides failed for %s", ap, exc_info=(type(e), e, e.__traceback__))
                 continue
+            blob = rec[offs[m]:offs[m + 1]].tobytes()
             if pool is not None:
-                saving.append((ap, converted, pool.submit("save", psfs, converted, timestamp_epoch)))
+                saving.append((ap, converted, pool.submit("save_records", blob, int(fmt), converted, timestamp_epoch)))
                 reap(8 * _IO_POOL["n"])
             else:
-                saving.append((ap, converted, _save_job(psfs, converted, timestamp_epoch)))
+                saving.append((ap, converted, _save_records_job(blob, int(fmt), converted, timestamp_epoch)))
                 reap(0)
-        del res, members
+        del rec, members
     reap(0)
     return {ap: done[ap] for ap in paths if ap in done}
+
+
+_FIND_PEPTIDES_KEYWORDS = ("median_filter_size", "correlation_matrix", "candidate_pixels", "c_std", "r_2_threshold",
+                           "consolidation_radius", "fit_type", "N_iter")
+
+
+def _check_find_peptides_parameters(fp):
+    """find_peptides(**fp) raises TypeError for a keyword it does not have (the reference's image_batch logs that per image,
+    pflib.py:957-964); find_peptides_records swallows unknown keywords, so the check is made here."""
+    for k in fp:
+        if k not in _FIND_PEPTIDES_KEYWORDS:
+            raise TypeError("find_peptides() got an unexpected keyword argument '%s'" % k)
 
 
 def parallel_image_batch(image_paths, find_peptides_parameters=None, timestamp_epoch=None, num_processes=None):

@@ -100,22 +100,37 @@ def test_read_image_16bit(tmp_path):
     assert out == str(tmp_path / "b.png") and np.array_equal(np.array(Image.open(out)), img)
 
 
+def records_of(psfs):
+    """A find_peptides dict -> the peak records (uint8[k, engine.PEAK_RECORD_BYTES]) whose records_to_dicts is that dict."""
+    from fluorosequencingimageanalysis_amd import engine
+    rec = np.zeros(len(psfs), engine.RECORD_DTYPE)
+    for r, ((kh, kw), v) in zip(rec, psfs.items()):
+        for name, x in zip(("h0", "w0", "H", "A", "sigma_h", "sigma_w", "theta"), v[:7]):
+            r[name] = x
+        r["sub"], r["fit"], r["rmse"], r["r2"], r["s_n"] = v[7], v[8], v[9], v[10], v[11]
+        r["key_h"], r["key_w"], r["h"], r["w"] = kh, kw, kh, kw
+    return rec.view(np.uint8).reshape(len(psfs), engine.PEAK_RECORD_BYTES)
+
+
 @pytest.fixture
 def fake_gpu(monkeypatch):
-    """find_peptides_batch stood in for: every field 'finds' the golden PSFs (records what it was called with)."""
-    from fluorosequencingimageanalysis_amd import pflib
+    """The GPU call of image_batch (find_peptides_records: byte tables, no dicts) stood in for: every field 'finds' the golden
+    PSFs (records what it was called with); a field whose first pixel is 7 'fails' the re-key assertion (count -1)."""
+    from fluorosequencingimageanalysis_amd import _native, pflib
     psfs, _ = golden_psfs()
+    one = records_of(psfs)
+    back = pflib.records_to_dicts(one, [len(one)])[0]
+    assert list(back) == list(psfs) and all(np.array_equal(np.asarray(a), np.asarray(b)) and type(a) is type(b)
+                                            for k in psfs for a, b in zip(back[k], psfs[k]))
     calls = []
 
-    def fake(images, errors='raise', **kw):
+    def fake(images, **kw):
         calls.append((np.asarray(images).shape, kw))
         if kw.get("fit_type", "gauss") != "gauss":
             raise NotImplementedError("monte_carlo")
-        out = []
-        for im in images:
-            out.append(AssertionError("re-key") if int(im[0, 0]) == 7 else dict(psfs))
-        return out
-    monkeypatch.setattr(pflib, "find_peptides_batch", fake)
+        counts = np.array([-1 if int(im[0, 0]) == 7 else len(one) for im in images], np.int32)
+        return np.concatenate([one for c in counts if c >= 0] or [one[:0]]), counts, _native.PIXELS_U16
+    monkeypatch.setattr(pflib, "find_peptides_records", fake)
     return calls
 
 

@@ -96,13 +96,15 @@ def _fake_gpu(pflib, fail_rank=None, rank=0):
     """Stand-ins for the two GPU entry points the file layer uses (as tests/test_batch_io.py does): every image 'finds' the
     golden PSFs; its candidate count is its top-left pixel."""
     import numpy as np
-    from test_batch_io import golden_psfs
+    from test_batch_io import golden_psfs, records_of
+    from fluorosequencingimageanalysis_amd import _native
     psfs, _ = golden_psfs()
+    one = records_of(psfs)
 
-    def fake_fit(images, errors='raise', **kw):
+    def fake_fit(images, **kw):                 # (image_batch's GPU call: byte tables, find_peptides_records)
         if fail_rank == rank:
             raise RuntimeError("device lost")
-        return [dict(psfs) for _ in images]
+        return np.concatenate([one for _ in images]), np.full(len(images), len(one), np.int32), _native.PIXELS_U16
 
     def fake_counts(paths, detect_parameters=None):
         out = []
@@ -112,7 +114,7 @@ def _fake_gpu(pflib, fail_rank=None, rank=0):
             except Exception:       # noqa: BLE001
                 out.append(None)
         return out
-    pflib.find_peptides_batch = fake_fit
+    pflib.find_peptides_records = fake_fit
     pflib._candidate_counts = fake_counts
 
 
