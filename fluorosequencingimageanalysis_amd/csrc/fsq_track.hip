@@ -18,7 +18,8 @@
 namespace {
 
 constexpr int TRK_SMAX = 32768;         // spots of one field (all frames) at most
-constexpr int TRK_FMAX = 64;            // frames at most
+constexpr int TRK_FLDS = 64;            // frame tables (cumulative offsets, first spot of every frame) of up to this many frames live
+                                        // in LDS; longer time series keep them in the caller's workspace (round 4: no frame limit)
 
 __device__ __forceinline__ long trk_py2_round(double x) { return (long)(x >= 0 ? __builtin_floor(x + 0.5) : __builtin_ceil(x - 0.5)); }
 
@@ -31,8 +32,8 @@ __host__ __device__ inline size_t trk_pairs_bytes(long long pair_cap) { return (
 
 struct TrkShared {
     unsigned a_taken[TRK_SMAX / 32], d_taken[TRK_SMAX / 32];
-    double cum[TRK_FMAX][2];
-    int fs[TRK_FMAX + 1];
+    double cum[TRK_FLDS][2];
+    int fs[TRK_FLDS + 1];
     int np, ndisc, status, nheads;
 };
 
@@ -42,7 +43,8 @@ __global__ void __launch_bounds__(256) k8_track(const int32_t* __restrict__ hw, 
                                                 int32_t* __restrict__ prev, int32_t* __restrict__ next, uint8_t* __restrict__ kept,
                                                 int32_t* __restrict__ traces, int32_t* __restrict__ n_traces,
                                                 int32_t* __restrict__ n_disc, int32_t* __restrict__ status_out,
-                                                int32_t* __restrict__ grids, unsigned char* __restrict__ pair_ws, int pair_cap)
+                                                int32_t* __restrict__ grids, unsigned char* __restrict__ pair_ws, int pair_cap,
+                                                double* __restrict__ frame_ws)
 {
     __shared__ TrkShared S;
     const int fld = blockIdx.x, t = threadIdx.x;
@@ -60,18 +62,21 @@ __global__ void __launch_bounds__(256) k8_track(const int32_t* __restrict__ hw, 
     int32_t* my_prev = prev + s0;
     int32_t* my_next = next + s0;
     uint8_t* my_kept = kept + s0;
+    // frame tables: cum[f] = the offsets accumulated up to frame f, fs[f] = number of the first spot of frame f
+    double* cum = (F <= TRK_FLDS) ? &S.cum[0][0] : frame_ws + (size_t)fld * ((size_t)F * 2 + (size_t)(F + 2) / 2 + 1);
+    int* fs = (F <= TRK_FLDS) ? S.fs : (int*)(cum + (size_t)F * 2);
+    const double* off = offsets + (size_t)fld * F * 2;
     if (t == 0) {
         S.np = 0; S.ndisc = 0; S.status = 0; S.nheads = 0;
-        S.fs[0] = 0;
-        for (int f = 0; f < F; f++) S.fs[f + 1] = S.fs[f] + counts[(size_t)fld * F + f];
-        const double* off = offsets + (size_t)fld * F * 2;
+        fs[0] = 0;
+        for (int f = 0; f < F; f++) fs[f + 1] = fs[f] + counts[(size_t)fld * F + f];
         if (off[0] != 0.0 || off[1] != 0.0) S.status = FSQ_EINVAL;          // ValueError, flexlibrary.py:581-583
-        if (S.fs[F] != n || n > TRK_SMAX) S.status = FSQ_EINVAL;
-        for (int f = 0; f < F; f++) {                   // accumulate_offsets: a fresh left-to-right sum per frame
-            double sh = 0.0, sw = 0.0;
-            for (int g = 0; g <= f; g++) { sh = sh + off[2 * g]; sw = sw + off[2 * g + 1]; }
-            S.cum[f][0] = sh; S.cum[f][1] = sw;
-        }
+        if (fs[F] != n || n > TRK_SMAX) S.status = FSQ_EINVAL;
+    }
+    for (int f = t; f < F; f += 256) {                  // accumulate_offsets: a fresh left-to-right sum per frame (flexlibrary.py:585-600)
+        double sh = 0.0, sw = 0.0;
+        for (int g = 0; g <= f; g++) { sh = sh + off[2 * g]; sw = sw + off[2 * g + 1]; }
+        cum[2 * f] = sh; cum[2 * f + 1] = sw;
     }
     for (int k = t; k < TRK_SMAX / 32; k += 256) { S.a_taken[k] = 0; S.d_taken[k] = 0; }
     __syncthreads();
@@ -79,8 +84,12 @@ __global__ void __launch_bounds__(256) k8_track(const int32_t* __restrict__ hw, 
         if (t == 0) { status_out[fld] = S.status; n_traces[fld] = 0; n_disc[fld] = 0; }
         return;
     }
-    auto frame_of = [&](int i) { int f = 0; while (i >= S.fs[f + 1]) f++; return f; };
-    auto pos = [&](int i, int f, double* h, double* w) { *h = my_hw[2 * i] + S.cum[f][0]; *w = my_hw[2 * i + 1] + S.cum[f][1]; };
+    auto frame_of = [&](int i) {                        // the frame whose spots include number i (fs is non-decreasing)
+        int lo = 0, hi = F - 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (i >= fs[mid + 1]) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    auto pos = [&](int i, int f, double* h, double* w) { *h = my_hw[2 * i] + cum[2 * f]; *w = my_hw[2 * i + 1] + cum[2 * f + 1]; };
     auto cell_of = [&](int i, int f) {
         double h, w; pos(i, f, &h, &w);
         return (int)(trk_py2_round(h) * W + trk_py2_round(w));
@@ -91,7 +100,7 @@ __global__ void __launch_bounds__(256) k8_track(const int32_t* __restrict__ hw, 
         double oh, ow; pos(i, f, &oh, &ow);
         bool ok = true;
         for (int g = 0; g < F && ok; g++) {
-            const double gh = oh - S.cum[g][0], gw = ow - S.cum[g][1];
+            const double gh = oh - cum[2 * g], gw = ow - cum[2 * g + 1];
             ok = (spot_radius <= gh && gh < H - 0.5 - spot_radius && spot_radius <= gw && gw < W - 0.5 - spot_radius);
         }
         my_kept[i] = ok ? 1 : 0;
@@ -101,10 +110,10 @@ __global__ void __launch_bounds__(256) k8_track(const int32_t* __restrict__ hw, 
     __syncthreads();
     // ---- two spots of one frame in one bin: the reference's assert (flexlibrary.py:851-856) ---------------------
     for (int f = 0; f < F; f++) {
-        for (int i = S.fs[f] + t; i < S.fs[f + 1]; i += 256)
+        for (int i = fs[f] + t; i < fs[f + 1]; i += 256)
             if (my_kept[i] && atomicCAS(&bins[cell_of(i, f)], -1, i) != -1) S.status = FSQ_EASSERT;
         __syncthreads();
-        for (int i = S.fs[f] + t; i < S.fs[f + 1]; i += 256)
+        for (int i = fs[f] + t; i < fs[f + 1]; i += 256)
             if (my_kept[i]) bins[cell_of(i, f)] = -1;
         __syncthreads();
     }
@@ -114,13 +123,13 @@ __global__ void __launch_bounds__(256) k8_track(const int32_t* __restrict__ hw, 
     }
     // ---- main loop (flexlibrary.py:858-971) ---------------------------------------------------------------------
     for (int f = 1; f < F; f++) {
-        for (int i = S.fs[f - 1] + t; i < S.fs[f]; i += 256)           // merge frame f - 1 into the ancestor cache
+        for (int i = fs[f - 1] + t; i < fs[f]; i += 256)           // merge frame f - 1 into the ancestor cache
             if (my_kept[i]) cache[cell_of(i, f - 1)] = i;
-        for (int i = S.fs[f] + t; i < S.fs[f + 1]; i += 256)           // bins of frame f
+        for (int i = fs[f] + t; i < fs[f + 1]; i += 256)           // bins of frame f
             if (my_kept[i]) bins[cell_of(i, f)] = i;
         if (t == 0) S.np = 0;
         __syncthreads();
-        for (int a = t; a < S.fs[f]; a += 256) {                        // every live ancestor looks at its window
+        for (int a = t; a < fs[f]; a += 256) {                        // every live ancestor looks at its window
             if (!my_kept[a]) continue;
             const int af = frame_of(a);
             double a_h, a_w; pos(a, af, &a_h, &a_w);
@@ -172,7 +181,7 @@ __global__ void __launch_bounds__(256) k8_track(const int32_t* __restrict__ hw, 
                 cache[(unsigned)(P.key2[i] >> 32)] = -1;
             }
         }
-        for (int i = S.fs[f] + t; i < S.fs[f + 1]; i += 256)           // bins back to empty
+        for (int i = fs[f] + t; i < fs[f + 1]; i += 256)           // bins back to empty
             if (my_kept[i]) bins[cell_of(i, f)] = -1;
         __syncthreads();
     }
@@ -287,10 +296,13 @@ __global__ void kx87check(const double* __restrict__ dh, const double* __restric
 
 }  // namespace
 
-extern "C" int64_t fsq_track_workspace_bytes(int n_fields, int H, int W, int64_t pair_cap)
+// per field: two bin grids, the candidate-pair list of one frame, and - for time series of more than TRK_FLDS frames - the frame tables
+static int64_t trk_frame_doubles(int n_frames) { return n_frames <= TRK_FLDS ? 0 : (int64_t)n_frames * 2 + ((int64_t)n_frames + 2) / 2 + 1; }
+extern "C" int64_t fsq_track_workspace_bytes(int n_fields, int n_frames, int H, int W, int64_t pair_cap)
 {
-    if (n_fields < 1 || H < 1 || W < 1 || pair_cap < 1) return FSQ_EINVAL;
-    return (int64_t)n_fields * 2 * H * W * 4 + (int64_t)n_fields * (int64_t)trk_pairs_bytes(pair_cap);
+    if (n_fields < 1 || n_frames < 1 || H < 1 || W < 1 || pair_cap < 1) return FSQ_EINVAL;
+    return (int64_t)n_fields * 2 * H * W * 4 + (((int64_t)n_fields * (int64_t)trk_pairs_bytes(pair_cap) + 7) & ~(int64_t)7) +
+           (int64_t)n_fields * trk_frame_doubles(n_frames) * 8;
 }
 
 extern "C" int fsq_greedy_tracking(const int32_t* d_hw, const int32_t* d_field_start, const int32_t* d_counts,
@@ -301,14 +313,16 @@ extern "C" int fsq_greedy_tracking(const int32_t* d_hw, const int32_t* d_field_s
 {
     if (n_fields < 1 || n_frames < 1 || H < 1 || W < 1 || candidate_radius < 0 || !(spot_radius >= 0)) return FSQ_EINVAL;
     if (!d_field_start || !d_counts || !d_offsets || !d_n_traces || !d_n_discarded || !d_status || !d_workspace) return FSQ_EINVAL;
-    if (n_frames > TRK_FMAX || (long long)H * W >= (1ll << 31)) return FSQ_ENOTIMPL;
+    if ((long long)H * W >= (1ll << 31)) return FSQ_ENOTIMPL;
     if (pair_cap < 1 || pair_cap > 2000000000ll) return FSQ_EINVAL;
-    if (workspace_bytes < fsq_track_workspace_bytes(n_fields, H, W, pair_cap)) return FSQ_ENOMEM;
+    if (workspace_bytes < fsq_track_workspace_bytes(n_fields, n_frames, H, W, pair_cap)) return FSQ_ENOMEM;
     hipStream_t s = (hipStream_t)stream;
     FSQ_HIP_CHECK(hipMemsetAsync(d_workspace, 0xFF, (size_t)n_fields * 2 * H * W * 4, s));
+    unsigned char* pair_ws = (unsigned char*)d_workspace + (size_t)n_fields * 2 * H * W * 4;
+    double* frame_ws = (double*)(pair_ws + (((size_t)n_fields * trk_pairs_bytes(pair_cap) + 7) & ~(size_t)7));
     hipLaunchKernelGGL(k8_track, dim3(n_fields), dim3(256), 0, s, d_hw, d_field_start, d_counts, d_offsets, n_frames, H, W,
                        candidate_radius, spot_radius, d_prev, d_next, d_kept, d_traces, d_n_traces, d_n_discarded, d_status,
-                       (int32_t*)d_workspace, (unsigned char*)d_workspace + (size_t)n_fields * 2 * H * W * 4, (int)pair_cap);
+                       (int32_t*)d_workspace, pair_ws, (int)pair_cap, frame_ws);
     FSQ_HIP_CHECK(hipGetLastError());
     return FSQ_OK;
 }

@@ -50,9 +50,8 @@ def track_fields(fields, offsets, frame_shape, candidate_radius=2, spot_radius=0
     hw = np.ascontiguousarray(np.concatenate(parts) if parts else np.zeros((0, 2), np.int32))
     start = np.concatenate([[0], np.cumsum(counts.sum(axis=1))]).astype(np.int32)
     total = int(start[-1])
-    # the kernel's limits (csrc/fsq_track.hip: one block walks a field with its spot flags in LDS); the reference has none
-    if F > TRACK_MAX_FRAMES:
-        raise NotImplementedError("greedy tracking on the GPU handles at most %d frames per field (got %d)" % (TRACK_MAX_FRAMES, F))
+    # the kernel's limit (csrc/fsq_track.hip: one block walks a field with its spot flags in LDS); the reference has none.
+    # (The number of frames is unlimited since round 4: the frame tables of long time series live in the workspace.)
     if counts.size and int(counts.sum(axis=1).max()) > TRACK_MAX_SPOTS:
         raise NotImplementedError("greedy tracking on the GPU handles at most %d spots per field, all frames together (got %d)"
                                   % (TRACK_MAX_SPOTS, int(counts.sum(axis=1).max())))
@@ -79,11 +78,11 @@ def track_fields(fields, offsets, frame_shape, candidate_radius=2, spot_radius=0
     return out
 
 
-TRACK_MAX_FRAMES, TRACK_MAX_SPOTS = 64, 32768
+TRACK_MAX_SPOTS = 32768
 
 
 def _track_launch(torch, dev, L, hw, start, counts, off, n_fields, F, H, W, candidate_radius, spot_radius, pair_cap, total):
-    ws_bytes = L.fsq_track_workspace_bytes(n_fields, H, W, pair_cap)
+    ws_bytes = L.fsq_track_workspace_bytes(n_fields, F, H, W, pair_cap)
     if ws_bytes < 0:
         raise ValueError("invalid tracking shape")
     t = lambda a: torch.from_numpy(a).to(dev)          # noqa: E731

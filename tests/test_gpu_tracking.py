@@ -87,12 +87,47 @@ def test_tracking_errors(env):
         fl.Experiment.accumulate_offsets([(0, 1), (0, 0)])
     with pytest.raises(TypeError):
         fl.Experiment.greedy_particle_tracking([[]], (8, 8))
-    # the kernel's limits are named (the reference has none): 64 frames, 32 768 spots per field
-    with pytest.raises(NotImplementedError, match="64 frames"):
-        fl.track_fields([[np.zeros((0, 2), np.int32)] * 65], [[(0, 0)] * 65], (12, 12))
+    # the kernel's limit is named (the reference has none): 32 768 spots per field
     lattice = np.array([(h, w) for h in range(182) for w in range(182)], np.int32)          # 33 124 spots in one frame
     with pytest.raises(NotImplementedError, match="32768 spots"):
         fl.track_fields([[lattice]], [[(0, 0)]], (200, 200))
+
+
+def test_long_time_series_equal_the_oracle(env):
+    """More than 64 frames per field (the kernel's LDS frame tables end there; round 4 keeps the tables of longer series in the
+    workspace): 150 frames of drifting, blinking spots with accumulating sub-pixel offsets in two fields of one launch, and a
+    65-frame series of empty frames, against the oracle tracker (itself pinned to the reference's traces, tests/test_tracking.py)."""
+    torch, N, fl, O = env
+    rng = np.random.default_rng(404)
+    H = W = 96
+    fields, offsets = [], []
+    for fld in range(2):
+        F = 150 if fld == 0 else 97
+        base = np.stack([rng.integers(8, H - 8, 40), rng.integers(8, W - 8, 40)], axis=1)
+        drift = np.cumsum(rng.uniform(-0.4, 0.4, (F, 2)), axis=0)
+        frames, offs = [], [(0.0, 0.0)]
+        for f in range(F):
+            on = rng.random(len(base)) > 0.2                               # a fifth of the spots is dark in any frame
+            hw = np.unique(np.rint(base[on] + drift[f] + rng.integers(-1, 2, (int(on.sum()), 2))).astype(np.int32), axis=0)
+            frames.append(hw)
+            if f:
+                offs.append((float(-(drift[f] - drift[f - 1])[0]), float(-(drift[f] - drift[f - 1])[1])))
+        fields.append(frames)
+        offsets.append(offs)
+    # (fields of one launch share a frame count: the shorter series is padded with empty frames)
+    F = max(len(x) for x in fields)
+    for frames, offs in zip(fields, offsets):
+        while len(frames) < F:
+            frames.append(np.zeros((0, 2), np.int32))
+            offs.append((0.0, 0.0))
+    got = fl.track_fields(fields, offsets, (H, W), candidate_radius=3)
+    for (tr, nd, prev, nxt, kept), frames, offs in zip(got, fields, offsets):
+        o_tr, o_nd, o_prev, o_next, o_kept = O.greedy_tracking(frames, offs, (H, W), 3, 0)
+        assert nd == o_nd and np.array_equal(kept, o_kept)
+        assert np.array_equal(prev, o_prev) and np.array_equal(nxt, o_next) and np.array_equal(tr, o_tr)
+        assert tr.shape[1] == F and len(tr) > 40 and (np.sum(tr >= 0, axis=1) > 20).any()      # long traces exist
+    empty = fl.track_fields([[np.zeros((0, 2), np.int32)] * 65], [[(0, 0)] * 65], (12, 12))[0]
+    assert empty[0].shape == (0, 65) and empty[1] == 0
 
 
 def test_pair_list_grows_on_demand(env):

@@ -38,7 +38,7 @@ hw = np.ascontiguousarray(np.concatenate(parts), dtype=np.int32)
 start = np.concatenate([[0], np.cumsum(counts.sum(axis=1))]).astype(np.int32)
 total = int(start[-1])
 pair_cap = 8 * int(counts.max())
-ws = torch.empty(L.fsq_track_workspace_bytes(n_fields, H, W, pair_cap), dtype=torch.uint8, device=dev)
+ws = torch.empty(L.fsq_track_workspace_bytes(n_fields, F, H, W, pair_cap), dtype=torch.uint8, device=dev)
 t = lambda a: torch.from_numpy(a).to(dev)      # noqa: E731
 d_hw, d_start, d_counts, d_off = t(hw.reshape(-1)), t(start), t(counts.reshape(-1)), t(offs.reshape(-1))
 d_prev, d_next = torch.empty(total, dtype=torch.int32, device=dev), torch.empty(total, dtype=torch.int32, device=dev)
