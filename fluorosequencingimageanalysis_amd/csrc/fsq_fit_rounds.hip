@@ -53,7 +53,10 @@ __device__ unsigned long long g_rphase[32];
 // ---- data layout in HBM ------------------------------------------------------------------------------
 // Work queues are structure-of-arrays indexed by QUEUE POSITION, so a wave reads its 64 (kB) or 16 (kA)
 // records with fully coalesced loads; a fit's live state travels with it from queue to queue:
-//   queue A record (input of kA):  idx | x[7] | diag[7] | llim1 fnorm par delta xnorm | niter,nfev      21 x 8 B
+//   queue A record (input of kA):  idx | x[7] | diag[7] | llim1 fnorm par delta xnorm | niter,nfev | E[25]   46 x 8 B
+//                                  (E = exp(-(u^2 + v^2) / 2) of the 25 model pixels at x, written by the step round on acceptance:
+//                                  kA rebuilds fvec = data - (x0 + x1 E) from it.  Until round 4 E lived in a by-candidate array,
+//                                  which the step round - one lane per fit - wrote with 25 stores of 64 scattered 8-byte pieces each)
 //   queue B record (input of kB):  the same 21 + gnorm | ipvt | qtf[7] | sdiag[7] | R upper[28]          65 x 8 B
 //   queue C record (kB, resumed):  the same 65 + parl paru fp | lmpar iterations done                    69 x 8 B
 //   slow queue (plain-division kA): copies of queue-A records of fits that left the guarded operand ranges
@@ -69,7 +72,7 @@ __device__ unsigned long long g_rphase[32];
 enum { CNT_A = 0, CNT_BLO = 1, CNT_BHI = 2, CNT_C1 = 3, CNT_C3 = 4, CNT_SET = 8 };
 enum { Q_EPS = Q_WA3 };           // kA, during qrfac: relative error bounds of the tracked column norms (by logical position)
 enum { A_IDX = 0, A_X = 1, A_DIAG = 8, A_LLIM1 = 15, A_FNORM = 16, A_PAR = 17, A_DELTA = 18, A_XNORM = 19, A_ITER = 20,
-       A_LEN = 21,
+       A_HDR = 21 /* the part every kind of record starts with */, A_E = 21 /* queue A only: the model's 25 exponentials E at x */, A_LEN = 46,
        B_GNORM = 21, B_IPVT = 22, B_QTF = 23, B_SDIAG = 30, B_R = 37, B_LEN = 65,
        // a fit parked in the middle of lmpar (queue C): the B record as it stands plus the Newton state on par
        C_PARL = 65, C_PARU = 66, C_FP = 67, C_LMIT = 68, C_LEN = 69 };
@@ -87,7 +90,6 @@ struct FitStat {              // by candidate: ROI statistics (kinit)
 // The round kernels only ever see slots - fits of several batches share the queues and the launches.
 struct Ctx {
     uint16_t* roi;            // [pool][32]: the 25 pixels of every ROI, gathered once by kinit (64 bytes per fit)
-    double* fvec;             // [pool][25]: E = exp(-(u^2 + v^2) / 2) of the 25 model pixels at the current x (fvec = data - (x0 + x1 E))
     FitOut* out;              // [pool]
     FitStat* stat;            // [pool]
     long long cap;            // queue capacity (positions)
@@ -377,7 +379,7 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
     constexpr int G = 64 / L;                   // fits per wave
     constexpr int NC = 8 / L;                   // columns per lane
     constexpr int MPX = (FSQ_NPIX + L - 1) / L; // pixels per lane when a 25-pixel job is split over the group
-    constexpr int MREC = (A_LEN + L - 1) / L;   // record fields per lane
+    constexpr int MREC = (A_HDR + L - 1) / L;   // record fields per lane (the header; E is fetched by pixel)
     __shared__ double lds[Q_KA_END * G];
     const int lane = threadIdx.x, grp = lane / L, cl = lane % L, gbase = lane - cl;
     const int n7 = FSQ_NP;
@@ -397,7 +399,7 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
         const NtQ qa = ntq(QA + (active ? base + grp : 0));
         double rec[MREC];                   // fields cl, cl + L, ... of the 21-field queue-A record
 #pragma unroll
-        for (int m = 0; m < MREC; m++) { const int f = cl + L * m; rec[m] = (active && f < A_LEN) ? (double)qa[f * cap] : 0.0; }
+        for (int m = 0; m < MREC; m++) { const int f = cl + L * m; rec[m] = (active && f < A_HDR) ? (double)qa[f * cap] : 0.0; }
         bool hz = false, qhz = false;     // FAST: some operand left the range in which fsq_div_by == `/`
         int emin = 0;                     // FAST: smallest exponent among the tracked numerators
         int tag, niter, nfev, hist;
@@ -433,7 +435,7 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
             }
             if (!fresh) {
 #pragma unroll
-                for (int m = 0; m < MPX; m++) { const int k = cl + L * m; if (k < FSQ_NPIX) ev[m] = nt_ld(c.fvec + (size_t)idx * FSQ_NPIX + k); }
+                for (int m = 0; m < MPX; m++) { const int k = cl + L * m; if (k < FSQ_NPIX) ev[m] = qa[(A_E + k) * cap]; }
             }
 #pragma unroll
             for (int m = 0; m < MREC; m++) {    // fields 1..19 -> LDS slots 0..18: x | diag | llim1 fnorm par delta xnorm (Q_X, Q_DIAG, Q_TMP[0..4])
@@ -447,7 +449,7 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
             // ---- fdjac2 (mpfit.py:1512-1612): slot s = column s of the Jacobian, slot 7 = f(x) itself -------------
             // The model is g = p0 + p1 * E with E = exp(-(u^2 + v^2) / 2) a function of p2..p6 only, so the columns of p0
             // and p1 and f(x) itself need no new exp: they follow from E at the current point, which is what the step
-            // round leaves in c.fvec (fvec = data - (x0 + x1 * E) is rebuilt from it with the operations that produced it).
+            // round leaves in the queue-A record (fvec = data - (x0 + x1 * E) is rebuilt from it with the operations that produced it).
             // The five columns that do need the model (c2, c3, sigma4, sigma5, theta) are evaluated split by PIXEL over the
             // group - lane cl takes pixels cl, cl + L, ... for every column - and handed to the lanes that own the columns
             // through the staging slots.
@@ -494,7 +496,6 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
                             const double xp = x * cs - y * sn, yp = x * sn + y * cs;
                             const double E = ka_gauss<FAST>(rcx - xp, rcy - yp, k4, k5, &emin, &bad);
                             QL(Q_FVEC, i) = E;
-                            nt_st(c.fvec + (size_t)idx * FSQ_NPIX + i, E);
                         }
                     }
                 }
@@ -953,7 +954,7 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
 #endif
 // The trial evaluation f(wa2) of the step round (mpfit.py:1245): E = exp(-(u^2 + v^2) / 2) of the 25 model pixels into the
 // lane's LDS column (the residuals data - (p0 + p1 * E) are formed by the caller; E is also what an accepted step leaves
-// in c.fvec for the next Jacobian round).
+// in the queue-A record for the next Jacobian round).
 // FAST: the model's two divisions per pixel share their divisors (sigma_h, sigma_w, inside [0.75, 2] by the bounds) ->
 // fsq_div_by, and exp is the branch-free fsq_exp_bf; the operand ranges in which those equal `/` and exp() bit for bit
 // are checked on the way and the return value is true when one was left - the caller then repeats the evaluation with
@@ -1252,8 +1253,6 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
                 double t = q.dg[k] * wa2[k];
                 xs = fsq_fma(t, t, xs);
             }
-#pragma unroll
-            for (int i = 0; i < FSQ_NPIX; i++) if (live) nt_st(c.fvec + (size_t)tag_slot(c, tag) * FSQ_NPIX + i, myscr[kb_res_slot(i) * 64]);
             xnorm = fsq_sqrt(xs);
             fnorm = fnorm1;
             niter = niter + 1;
@@ -1299,6 +1298,10 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
                 for (int k = 0; k < FSQ_NP; k++) { qn[(A_X + k) * cap] = xq[k]; qn[(A_DIAG + k) * cap] = q.dg[k]; }
                 qn[A_LLIM1 * cap] = llim1; qn[A_FNORM * cap] = fnorm; qn[A_PAR * cap] = par; qn[A_DELTA * cap] = delta;
                 qn[A_XNORM * cap] = xnorm; qn[A_ITER * cap] = pack2(niter, nfev);
+                if (toA) {      // E at the accepted point travels with the record (coalesced: the lanes' positions are consecutive)
+#pragma unroll
+                    for (int i = 0; i < FSQ_NPIX; i++) qn[(A_E + i) * cap] = myscr[kb_res_slot(i) * 64];
+                }
                 if (toB) {
                     qn[B_GNORM * cap] = KB_GNORM(); qn[B_IPVT * cap] = pack2((int)ipvt, 0);
 #pragma unroll
@@ -1581,7 +1584,7 @@ size_t layout_bytes(size_t pool, size_t qcap)
 {
     qcap = cap_round(qcap);
     size_t b = 4096;
-    b += al256(pool * 64) + al256(pool * FSQ_NPIX * 8) + al256(pool * sizeof(FitOut)) + al256(pool * sizeof(FitStat));
+    b += al256(pool * 64) + al256(pool * sizeof(FitOut)) + al256(pool * sizeof(FitStat));
     b += 2 * al256(qcap * A_LEN * 8) + 2 * al256(qcap * B_LEN * 8) + 2 * al256(qcap * C_LEN * 8) + al256(qcap * A_LEN * 8);
     return b;
 }
@@ -1618,7 +1621,6 @@ struct FsqFitQueue {
         size_t o = 4096;
         c.cap = (long long)qcap;
         c.roi = (uint16_t*)(ws + o); o += al256(pool * 64);
-        c.fvec = (double*)(ws + o); o += al256(pool * FSQ_NPIX * 8);
         c.out = (FitOut*)(ws + o); o += al256(pool * sizeof(FitOut));
         c.stat = (FitStat*)(ws + o); o += al256(pool * sizeof(FitStat));
         QA[0] = (double*)(ws + o); o += al256(qcap * A_LEN * 8);
