@@ -409,6 +409,13 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
         const bool b_hi = hist > 1;
         const int at_lo = wave_reserve(cnt_cur + CNT_BLO, active && cl == 0 && !b_hi);
         const int at_hi = wave_reserve(cnt_cur + CNT_BHI, active && cl == 0 && b_hi);
+#ifdef FSQ_EXPERIMENT_EXTRA_ATOMICS_KA   // sensitivity of the round to the queue-tail atomics: N more per wave on the same cache line
+        {
+            int sink = 0;
+            for (int x = 0; x < FSQ_EXPERIMENT_EXTRA_ATOMICS_KA; x++) sink += wave_reserve(cnt_cur + 5 + (x & 1), active && cl == 0);
+            if (sink == 0x7fffffff) atomicMax(c.err, 99);
+        }
+#endif
         if (active && cl == 0) {      // (two lists in one array, growing towards each other)
             if (!b_hi) fsq_guard(c, at_lo, cap, G_KA_BLO); else fsq_guard(c, at_hi, cap, G_KA_BHI);
             if ((long long)at_lo + (long long)at_hi + 2 > cap && (at_lo > 0 || at_hi > 0)) {
@@ -1288,6 +1295,13 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
             // accepted -> a new Jacobian (queue A); rejected -> another pass with the same, mutated R (queue B)
             const bool toA = live && status == 0 && accepted, toB = live && status == 0 && !accepted;
             const bool hi = lm_hist > 1;
+#ifdef FSQ_EXPERIMENT_EXTRA_ATOMICS_KB
+            {
+                int sink = 0;
+                for (int x = 0; x < FSQ_EXPERIMENT_EXTRA_ATOMICS_KB; x++) sink += wave_reserve(cnt_next + 5 + (x & 1), live);
+                if (sink == 0x7fffffff) atomicMax(c.err, 99);
+            }
+#endif
             const int atA = (int)wave_reserve_checked(c, cnt_next + CNT_A, toA, cap, G_KB_A);
             const int atBl = (int)wave_reserve_checked(c, cnt_next + CNT_BLO, toB && !hi, cap, G_KB_BLO);
             const int atBh = (int)wave_reserve_checked(c, cnt_next + CNT_BHI, toB && hi, cap, G_KB_BHI);
