@@ -14,9 +14,13 @@
 //   k2_sqdev_chunks  sum((cm-mean)^2) per 8192-pixel chunk in numpy's pairwise order (bit-exact std)
 //   k2_threshold     per field: fold chunk sums left to right, thr = mean + c_std*sqrt(var)
 //   k2_count / k2_scan_field / k2_scan_all / k2_write   ordered stream compaction (no atomics)
+#include <algorithm>
+#include <cstdlib>
+
 #include "fsq_common.h"
 
 namespace {
+#include "fsq_median_net.h"
 
 constexpr int TW = 64, TH = 16;          // output tile of k1 (1024 px, 256 threads x 4 px)
 constexpr int MAXK = 9;                  // largest correlation matrix / median window side
@@ -161,6 +165,111 @@ __global__ void __launch_bounds__(256) k1_response(const uint16_t* __restrict__ 
         }
     }
     // block reduction of the exact integer sum, one atomic per block
+    __shared__ unsigned long long red[4];
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
+    if ((tid & 63) == 0) red[tid >> 6] = local;
+    __syncthreads();
+    if (tid == 0) atomicAdd(&field_sum[f], red[0] + red[1] + red[2] + red[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 for the default 5 x 5 median window (round 4).  Round 3's kernel spent half its time in the 25-sample selection
+// network (132 compare-exchanges per pixel on 25 LDS reads) and much of the rest in index arithmetic (a division and two
+// reflections with a modulo per staged pixel).  Here:
+//   * a block computes a fixed 16 x 64 region of the background-subtracted image mf (= 256 tasks of 4 horizontally adjacent
+//     pixels, one per thread) and from it the (16 - 2 kc) x (64 - 2 kc) responses its correlation windows fit into;
+//   * adjacent median windows share four of their five columns: a thread reads the 5 x 8 pixels of its four windows with ten
+//     8-byte LDS reads, sorts the eight columns once (9 compare-exchanges each) and selects each median from five sorted
+//     columns with the 66-comparator network of fsq_median_net.h (tools/gen_median_net.py: 108 min / max instructions);
+//   * all tile geometry is compile-time constant; the 'reflect' index is two compares (the modulo form only for images
+//     smaller than the halo);
+//   * a correlation matrix whose entries depend on the ring only (the default one, pflib.py:48-52) is applied as
+//     k_out (S5 - S3) + k_mid (S3 - c) + k_ctr c - the same integer, three multiplications instead of 25.
+constexpr int M5R = 16, M5C = 64;                // mf region of a block
+constexpr int R5R = M5R + 4, R5C = M5C + 4;      // raw region (median window reaches 2 pixels each way)
+
+__device__ __forceinline__ int reflect_fast(int i, int n)
+{
+    int g = i < 0 ? -1 - i : i;
+    g = g >= n ? 2 * n - 1 - g : g;
+    return ((unsigned)g < (unsigned)n) ? g : reflect_idx(i, n);
+}
+
+template <bool RING5>
+__global__ void __launch_bounds__(256) k1_response5(const uint16_t* __restrict__ img, int pix_fmt, int H, int W, DetectConst dc,
+                                                    long long* __restrict__ cm, unsigned long long* __restrict__ field_sum)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short raw[R5R * R5C];
+    __shared__ int mf[M5R * M5C];
+    const int ksz = RING5 ? 5 : dc.ksz, kc = (ksz - 1) / 2;
+    const int TH5 = M5R - 2 * kc, TW5 = M5C - 2 * kc;              // responses per block
+    const int f = blockIdx.z, tid = threadIdx.x;
+    const int h0 = blockIdx.y * TH5, w0 = blockIdx.x * TW5;
+    const uint16_t* im = img + (size_t)f * H * W;
+    for (int i = tid; i < R5R * R5C; i += 256) {                    // raw tile, scipy's 'reflect' indexing
+        const int rr = i / R5C, cc = i - rr * R5C;
+        const int gh = reflect_fast(h0 - kc - 2 + rr, H), gw = reflect_fast(w0 - kc - 2 + cc, W);
+        raw[i] = (unsigned short)fsq_pixel(im, (size_t)gh * W + gw, pix_fmt);
+    }
+    __syncthreads();
+    {   // mf = img - min(median, img); 0 outside the image (the correlation is zero padded)
+        const int r = tid >> 4, g4 = (tid & 15) * 4;
+        int col[8][5], ctr[4];
+#pragma unroll
+        for (int a = 0; a < 5; a++) {
+            const uint2* p = (const uint2*)(raw + (r + a) * R5C + g4);     // 8-byte aligned: R5C * 2 and g4 * 2 are multiples of 8
+            const uint2 lo = p[0], hi = p[1];
+            const unsigned w8[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+            for (int b = 0; b < 8; b++) col[b][a] = (int)((w8[b >> 1] >> (16 * (b & 1))) & 0xffffu);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) ctr[k] = col[k + 2][2];
+#pragma unroll
+        for (int b = 0; b < 8; b++) fsq_sort5(col[b][0], col[b][1], col[b][2], col[b][3], col[b][4]);
+        const int gh = h0 - kc + r;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int v[25];
+#pragma unroll
+            for (int b = 0; b < 5; b++)
+#pragma unroll
+                for (int a = 0; a < 5; a++) v[b * 5 + a] = col[k + b][a];
+            const int m = fsq_median_of_sorted_columns(v);
+            const int gw = w0 - kc + g4 + k;
+            const bool inside = gh >= 0 && gh < H && gw >= 0 && gw < W;
+            mf[r * M5C + g4 + k] = inside ? ctr[k] - min(m, ctr[k]) : 0;
+        }
+    }
+    __syncthreads();
+    unsigned long long local = 0;
+    for (int i = tid; i < TH5 * TW5; i += 256) {                     // zero-padded correlation, clamp at 0
+        const int rr = i / TW5, cc = i - rr * TW5;
+        const int gh = h0 + rr, gw = w0 + cc;
+        if (gh < H && gw < W) {
+            long long s;
+            if (RING5) {
+                int s5 = 0, s3 = 0;
+#pragma unroll
+                for (int a = 0; a < 5; a++)
+#pragma unroll
+                    for (int b = 0; b < 5; b++) {
+                        const int v = mf[(rr + a) * M5C + cc + b];
+                        s5 += v;
+                        if (a >= 1 && a <= 3 && b >= 1 && b <= 3) s3 += v;
+                    }
+                const int c0 = mf[(rr + 2) * M5C + cc + 2];
+                s = (long long)dc.K[0] * (long long)(s5 - s3) + (long long)dc.K[6] * (long long)(s3 - c0) + (long long)dc.K[12] * (long long)c0;
+            } else {
+                s = 0;
+                for (int a = 0; a < ksz; a++)
+                    for (int b = 0; b < ksz; b++) s += (long long)mf[(rr + a) * M5C + cc + b] * (long long)dc.K[a * ksz + b];
+            }
+            if (s < 0) s = 0;
+            cm[((size_t)f * H + gh) * W + gw] = s;
+            local += (unsigned long long)s;
+        }
+    }
     __shared__ unsigned long long red[4];
     for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
     if ((tid & 63) == 0) red[tid >> 6] = local;
@@ -456,7 +565,19 @@ extern "C" int fsq_detect(const uint16_t* d_img, int n_fields, int H, int W, con
         const int MH = TH + 2 * kc, MW = TW + 2 * kc, RH = MH + mo + me, RW = MW + mo + me;
         size_t shm = (((size_t)RH * RW * 2 + 15) & ~(size_t)15) + (size_t)MH * MW * 4;
         dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, n_fields);
-        if (med == 5) hipLaunchKernelGGL(k1_response<true>, grid, dim3(256), shm, s, d_img, prm->pixel_format, H, W, dc, cm, field_sum);
+        if (med == 5 && !getenv("FSQ_DETECT_R03")) {
+            // a correlation matrix whose entries depend on the ring only (the default one) needs three multiplications per pixel
+            bool ring = (ksz == 5);
+            for (int a = 0; a < 5 && ring; a++)
+                for (int b = 0; b < 5; b++) {
+                    const int d = std::max(abs(a - 2), abs(b - 2));
+                    if (dc.K[a * 5 + b] != (d == 2 ? dc.K[0] : d == 1 ? dc.K[6] : dc.K[12])) ring = false;
+                }
+            const int th5 = M5R - 2 * kc, tw5 = M5C - 2 * kc;
+            dim3 grid5((W + tw5 - 1) / tw5, (H + th5 - 1) / th5, n_fields);
+            if (ring) hipLaunchKernelGGL(k1_response5<true>, grid5, dim3(256), 0, s, d_img, prm->pixel_format, H, W, dc, cm, field_sum);
+            else hipLaunchKernelGGL(k1_response5<false>, grid5, dim3(256), 0, s, d_img, prm->pixel_format, H, W, dc, cm, field_sum);
+        } else if (med == 5) hipLaunchKernelGGL(k1_response<true>, grid, dim3(256), shm, s, d_img, prm->pixel_format, H, W, dc, cm, field_sum);
         else hipLaunchKernelGGL(k1_response<false>, grid, dim3(256), shm, s, d_img, prm->pixel_format, H, W, dc, cm, field_sum);
     }
     hipLaunchKernelGGL(k2_sqdev_chunks, dim3(n_chunks, n_fields), dim3(256), 0, s, cm, N, field_sum, n_chunks, chunk_sum);
