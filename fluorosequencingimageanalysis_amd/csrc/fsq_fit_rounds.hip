@@ -43,7 +43,9 @@ __device__ unsigned long long g_hz[32];
 __device__ unsigned long long g_rphase[32];
 #define RPH_DECL unsigned long long rph_t0 = clock64(), rph_acc[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};
 #define RPH_MARK(k) { unsigned long long t_ = clock64(); rph_acc[k] += t_ - rph_t0; rph_t0 = t_; }
-#define RPH_FLUSH(off) if (threadIdx.x == 0) { for (int k_ = 0; k_ < 16; k_++) atomicAdd(&g_rphase[(off) + k_], rph_acc[k_]); }
+// (one block in 64 reports: sixteen atomics per wave on two cache lines would themselves be the slowest thing in the kernel -
+// 88 atomics per microsecond and line chip-wide, DESIGN.md 4.2 - and the profile would measure its own traffic jam)
+#define RPH_FLUSH(off) if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) { for (int k_ = 0; k_ < 16; k_++) atomicAdd(&g_rphase[(off) + k_], rph_acc[k_]); }
 #else
 #define RPH_DECL
 #define RPH_MARK(k)
