@@ -644,12 +644,22 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
             }
             RPH_MARK(3)
             // ---- qrfac with column pivoting (mpfit.py:1748-1822), Q^T f fused in as slot 7 ----------
+            // Round 4 (production instantiation: FAST, 4 lanes): the tracked column norms, their reference values and their error
+            // bounds - rdiag, wa, eps, indexed by LOGICAL POSITION - live in registers, lane cl of the quad holding positions cl
+            // and cl + 4, instead of in LDS where every lane read all of them for every pivot choice (the pivot search was 14 % of
+            // the kernel's time for 4 % of its instructions: round trips to LDS in a dependent chain).  Maxima and the first
+            // position that attains them are quad reductions; a position's value is fetched from its owner with one shuffle.
+            constexpr bool REGPOS = FAST && (L == 4);
+            double prd[2] = {0., 0.}, pwa[2] = {0., 0.}, pep[2] = {0., 0.};
+            auto pos_get = [&](double a0, double a1, int p) { return __shfl((p >> 2) ? a1 : a0, gbase + (p & 3)); };
 #pragma unroll
             for (int pass = 0; pass < NC; pass++) {
                 const int slot = cl + L * pass;
                 if (slot < 7) {
                     const double nn = fsq_sqrt(dot_regcol(col[pass], 25));
-                    QL(Q_ACN, slot) = nn; QL(Q_RDIAG, slot) = nn; QL(Q_WA, slot) = nn; QL(Q_EPS, slot) = 0.;
+                    QL(Q_ACN, slot) = nn;
+                    if (REGPOS) { prd[pass] = nn; pwa[pass] = nn; pep[pass] = 0.; }
+                    else { QL(Q_RDIAG, slot) = nn; QL(Q_WA, slot) = nn; QL(Q_EPS, slot) = 0.; }
                 }
             }
             WAVE_SYNC();
@@ -657,7 +667,46 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
             bool broken = false;
             for (int j = 0; j < n7; j++) {
                 const int len = FSQ_NPIX - j;
-                if (!broken) {
+                if (REGPOS && !broken) {
+                    // candidates: positions j .. 6 (norms are >= +0; a NaN among them sends the fit to the exact kernel, where
+                    // numpy.max's order of comparisons is followed literally)
+                    double lm = -1.0;
+                    bool has_nan = false;
+#pragma unroll
+                    for (int m = 0; m < 2; m++) {
+                        const int p = cl + 4 * m;
+                        if (p >= j && p < n7) { has_nan = has_nan || (prd[m] != prd[m]); lm = (prd[m] > lm) ? prd[m] : lm; }
+                    }
+                    double rmax = lm;
+                    { const double o1 = __shfl_xor(rmax, 1); rmax = (o1 > rmax) ? o1 : rmax; const double o2 = __shfl_xor(rmax, 2); rmax = (o2 > rmax) ? o2 : rmax; }
+                    int lk = 99;
+#pragma unroll
+                    for (int m = 1; m >= 0; m--) {
+                        const int p = cl + 4 * m;
+                        if (p >= j && p < n7 && prd[m] == rmax) lk = p;
+                    }
+                    int kmax = min(lk, __shfl_xor(lk, 1));
+                    kmax = min(kmax, __shfl_xor(kmax, 2));
+                    if (kmax == 99) kmax = -1;
+                    KA_HZ(5, kmax < 0 || has_nan);
+                    const int kq = kmax < 0 ? j : kmax;
+                    const double em = pos_get(pep[0], pep[1], kq), low_m = rmax * (1. - em);
+#pragma unroll
+                    for (int m = 0; m < 2; m++) {
+                        const int p = cl + 4 * m;
+                        if (p >= j && p < n7 && p != kq) KA_HZ(6, (pep[m] != 0 || em != 0) && !(prd[m] * (1. + pep[m]) < low_m));
+                    }
+                    const double vj_rd = pos_get(prd[0], prd[1], j), vj_wa = pos_get(pwa[0], pwa[1], j), vj_ep = pos_get(pep[0], pep[1], j);
+                    if (kmax >= 0 && kmax != j) {
+                        int sj = nib_get(ipvt, j), sk = nib_get(ipvt, kmax);
+                        ipvt = nib_set(nib_set(ipvt, j, sk), kmax, sj);
+                        pos = nib_set(nib_set(pos, sk, j), sj, kmax);
+#pragma unroll
+                        for (int m = 0; m < 2; m++)
+                            if (cl + 4 * m == kmax) { prd[m] = vj_rd; pwa[m] = vj_wa; pep[m] = vj_ep; }
+                    }
+                }
+                if (!REGPOS && !broken) {
                     double rmax = QL(Q_RDIAG, j);
                     for (int k = j + 1; k < n7; k++) rmax = np_max2(rmax, QL(Q_RDIAG, k));
                     int kmax = -1;
@@ -774,10 +823,12 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
                 unsigned long long redo[NSUB];
 #pragma unroll
                 for (int sub = 0; sub < NSUB; sub++) {
-                    const int p = j + 1 + cl + L * sub;
+                    // (register-resident norms: lane cl looks after the positions it holds, cl and cl + 4; else the live positions
+                    // are dealt out in order, lane cl taking j + 1 + cl and j + 1 + L + cl)
+                    const int p = REGPOS ? cl + 4 * sub : j + 1 + cl + L * sub;
                     bool need = false;
-                    if (p < n7 && !broken && ajj0 != 0) {
-                        double rk = QL(Q_RDIAG, p);
+                    if (p > j && p < n7 && !broken && ajj0 != 0) {
+                        double rk = REGPOS ? prd[sub] : (double)QL(Q_RDIAG, p);
                         if (rk != 0 && !FAST) {
                             double temp = QL(Q_R, j * 7 + nib_get(ipvt, p)) / rk;
                             rk = rk * fsq_sqrt(np_max2(1. - fsq_pow2(temp), 0.));
@@ -793,7 +844,7 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
                             // re-computation test here and the pivot choice of the next steps - take into account; a decision
                             // the bound cannot settle sends the fit to the exact kernel (hz), like every other guarded range.
                             const double U = 1.1102230246251565e-16;
-                            const double e0 = QL(Q_EPS, p);
+                            const double e0 = REGPOS ? pep[sub] : (double)QL(Q_EPS, p);
                             const double t = QL(Q_R, j * 7 + nib_get(ipvt, p)) / rk;
                             const double sq = t * t, lo = fsq_fma(t, t, -sq);
                             const bool exact = (e0 == 0) && fsq_square_is_pow2(t, sq, lo);
@@ -805,7 +856,7 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
                             double e1 = 0.;
                             if (!exact && v > 0) e1 = e0 + 0.6 * dv * __builtin_amdgcn_rcp(v) + 4. * U;
                             KA_HZ(12, !(e1 < 1e-3));
-                            const double temp = rk1 / QL(Q_WA, p);
+                            const double temp = rk1 / (REGPOS ? pwa[sub] : (double)QL(Q_WA, p));
                             const double q = 0.05 * temp * temp;
                             if (e1 == 0) need = (q <= FSQ_MACHEP);
                             else {
@@ -814,7 +865,10 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
                                 else KA_HZ(14, !(q * (1. - qe) > FSQ_MACHEP));
                             }
                             if (c.force_redo) need = true;
-                            if (!need) { QL(Q_RDIAG, p) = rk1; QL(Q_EPS, p) = e1; }
+                            if (!need) {
+                                if (REGPOS) { prd[sub] = rk1; pep[sub] = e1; }
+                                else { QL(Q_RDIAG, p) = rk1; QL(Q_EPS, p) = e1; }
+                            }
                         }
                     }
                     redo[sub] = __ballot(need);
@@ -827,18 +881,30 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
                     for (int pass = 0; pass < NC; pass++) {
                         const int slot = cl + L * pass;
                         const int k = (slot < 7) ? nib_get(pos, slot) : 0;
-                        const int ix = k - j - 1;
-                        if (slot < 7 && ix >= 0 && ((redo[(NSUB == 2) ? ix / L : 0] >> (gbase + ix % L)) & 1ull)) {
+                        const int ix = REGPOS ? k : k - j - 1;      // (which lane looked at position k, and in which of its two turns)
+                        if (slot < 7 && k > j && ((redo[(NSUB == 2) ? ix / L : 0] >> (gbase + ix % L)) & 1ull)) {
                             const double rk = fsq_sqrt(dot_regcol_from1(col[pass], len));
                             QL(Q_WA, k) = rk;
                             QL(Q_RDIAG, k) = rk;
                             if (FAST) QL(Q_EPS, k) = 0.;            // an exact norm again
                         }
                     }
+                    if (REGPOS) {       // (rare: the column's owner has left the fresh norm in LDS for the lane that holds the position)
+                        WAVE_SYNC();
+#pragma unroll
+                        for (int sub = 0; sub < 2; sub++)
+                            if ((redo[sub] >> lane) & 1ull) { prd[sub] = QL(Q_WA, cl + 4 * sub); pwa[sub] = prd[sub]; pep[sub] = 0.; }
+                    }
                 }
                 RPH_MARK(10)
-                if (!broken) QL(Q_RDIAG, j) = QL(Q_TMP, 5);
-                QL(Q_R, j * 7 + lj) = QL(Q_RDIAG, j);               // fjac[j, lj] = rdiag[j] (mpfit.py:1123)
+                if (REGPOS) {
+                    double dj = QL(Q_TMP, 5);
+                    if (broken) dj = pos_get(prd[0], prd[1], j);
+                    QL(Q_R, j * 7 + lj) = dj;                       // fjac[j, lj] = rdiag[j] (mpfit.py:1123)
+                } else {
+                    if (!broken) QL(Q_RDIAG, j) = QL(Q_TMP, 5);
+                    QL(Q_R, j * 7 + lj) = QL(Q_RDIAG, j);           // fjac[j, lj] = rdiag[j] (mpfit.py:1123)
+                }
 #pragma unroll
                 for (int pass = 0; pass < NC; pass++) {
 #pragma unroll
