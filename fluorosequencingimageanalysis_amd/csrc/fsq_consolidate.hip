@@ -16,6 +16,9 @@
 // ONE wave: 21-30 ms for a 2 048^2 field of 46 000 candidates whatever the number of fields.)
 // A pixel -> candidate grid (int32 per pixel, workspace) plays the role of the reference's dict: -1 empty, i >= 0 the
 // entry of candidate i, -(i + 2) the deleted entry of candidate i.
+#include <algorithm>
+#include <cstdlib>
+
 #include "fsq_common.h"
 #include "fsq_devmath.h"
 
@@ -301,6 +304,257 @@ __global__ void __launch_bounds__(1024) k5_consolidate(FsqRow* __restrict__ rows
     if (tid == 0) nkeep[f] = s_assert ? -1 : nk0 + nk1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4, second form (the default): CONNECTED COMPONENTS.  Two candidates can only influence each other's turns if their
+// windows overlap - |dh| <= 2 (r + 2) and |dw| <= 2 (r + 2) - so the survivors fall into components of that relation which never
+// touch each other's cells, and within a component the turns are taken in raster order by ONE wave: no wave ever waits for
+// another, and the components of all fields (a 2 048^2 field has thousands: one survivor per ~600 pixels) spread over the
+// whole chip instead of over the 8 or 16 waves of one block.
+//   k5c_insert   filter (pflib.py:466), dict insertion into the pixel -> candidate grid, parent[i] = i
+//   k5c_union    every survivor looks at the raster-earlier half of its (4r+9)^2 neighbourhood and unites itself with every
+//                survivor it finds (lock-free union-find: roots are linked under smaller indices with a compare-and-swap,
+//                finds halve paths; all accesses to `parent` are relaxed device-scope atomics - no fence anywhere)
+//   k5c_flatten  parent[i] = root of i (the smallest index of the component), last[root] = its largest index
+//   k5c_turns    the wave that meets a root walks root .. last[root], picks the members out by their label and gives each
+//                its turn (the window scan of the block kernel above, without the waiting)
+//   k5c_finish   re-key + kept list per field (the block kernel's tail)
+__device__ __forceinline__ int ldA(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stA(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ int uf_find(int* P, int x)
+{
+    for (;;) {
+        const int p = ldA(P + x);
+        if (p == x) return x;
+        const int gp = ldA(P + p);
+        if (gp == p) return p;
+        stA(P + x, gp);                 // path halving (a racing link of x cannot be lost: x is not a root here)
+        x = gp;
+    }
+}
+// the same walk with ordinary loads: what it sees may be out of date (another XCD's links are not in this one's L2) - an older state
+// of a forest whose pointers only ever move towards smaller indices, so the node it ends at is a member of the same tree, which is all a
+// link needs; only the link itself has to be atomic
+__device__ int uf_find_plain(const int* P, int x)
+{
+    for (;;) {
+        const int p = P[x];
+        if (p == x) return x;
+        x = p;
+    }
+}
+__device__ void uf_union(int* P, int a, int b)
+{
+    a = uf_find_plain(P, a); b = uf_find_plain(P, b);    // first try on cached values (a device-scope atomic load is a trip to memory)
+    for (;;) {
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }
+        if (atomicCAS(P + a, a, b) == a) return;        // the larger root goes under the smaller one: parent[x] <= x always, no cycles
+        a = uf_find(P, a); b = uf_find(P, b);           // a was no root any more: look again, this time at memory
+    }
+}
+
+struct K5Field { int off, cnt; FsqRow* R; int* grid; int* parent; int* last; };
+__device__ __forceinline__ K5Field k5_field(FsqRow* rows, const int* counts, const int* offsets, int f, int H, int W, int* ws, long long stride)
+{
+    K5Field F;
+    F.off = offsets[f]; F.cnt = counts[f]; F.R = rows + F.off;
+    int* base = ws + (size_t)f * stride;
+    F.grid = base; F.parent = base + (size_t)H * W; F.last = base + 2 * (size_t)H * W;
+    return F;
+}
+
+// grid = (blocks per field, n_fields), block = 64
+__global__ void __launch_bounds__(64) k5c_insert(FsqRow* __restrict__ rows, const int* __restrict__ counts, const int* __restrict__ offsets,
+                                                 int H, int W, double r2_thr, int* __restrict__ ws, long long stride)
+{
+    const K5Field F = k5_field(rows, counts, offsets, blockIdx.y, H, W, ws, stride);
+    for (int i = blockIdx.x * 64 + threadIdx.x; i < F.cnt; i += gridDim.x * 64) {
+        F.R[i].key_h = -1; F.R[i].key_w = -1;
+        const bool surv = !(F.R[i].r2 < r2_thr);
+        F.parent[i] = surv ? i : -1;
+        F.last[i] = i;
+        if (surv) F.grid[(size_t)F.R[i].h * W + F.R[i].w] = i;       // pre-set to -1
+    }
+}
+
+__global__ void __launch_bounds__(64) k5c_union(FsqRow* __restrict__ rows, const int* __restrict__ counts, const int* __restrict__ offsets,
+                                                int H, int W, int radius, int* __restrict__ ws, long long stride)
+{
+    const K5Field F = k5_field(rows, counts, offsets, blockIdx.y, H, W, ws, stride);
+    const int lane = threadIdx.x, D = 2 * (radius + 2);
+    for (int cbase = blockIdx.x * 64; cbase < F.cnt; cbase += gridDim.x * 64) {
+        const int ci = cbase + lane;
+        int c_h = 0, c_w = 0;
+        bool surv = false;
+        if (ci < F.cnt) { surv = ldA(F.parent + ci) >= 0; c_h = F.R[ci].h; c_w = F.R[ci].w; }
+        unsigned long long m = __ballot(surv);
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int i = cbase + src, h = __shfl(c_h, src), w = __shfl(c_w, src);
+            const int nh_lo = max(0, h - D), nw_lo = max(0, w - D), nw_hi = min(W, w + D + 1);
+            const int nww = nw_hi - nw_lo, nearly = (h - nh_lo) * nww + (w - nw_lo);       // the raster-earlier cells of the neighbourhood
+            for (int base = 0; base < nearly; base += 64 * 5) {
+                int kk[5];
+#pragma unroll
+                for (int g = 0; g < 5; g++) {
+                    const int c = base + 64 * g + lane;
+                    kk[g] = (c < nearly) ? F.grid[(size_t)(nh_lo + c / nww) * W + (nw_lo + c % nww)] : -1;
+                }
+#pragma unroll
+                for (int g = 0; g < 5; g++)
+                    if (kk[g] >= 0) uf_union(F.parent, i, kk[g]);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) k5c_flatten(const int* __restrict__ counts, const int* __restrict__ offsets, int H, int W,
+                                                  int* __restrict__ ws, long long stride)
+{
+    const int f = blockIdx.y, cnt = counts[f];
+    int* base = ws + (size_t)f * stride;
+    int* parent = base + (size_t)H * W;
+    int* last = base + 2 * (size_t)H * W;
+    for (int i = blockIdx.x * 64 + threadIdx.x; i < cnt; i += gridDim.x * 64) {
+        if (ldA(parent + i) < 0) continue;
+        int r = i;
+        for (;;) { const int p = ldA(parent + r); if (p == r) break; r = p; }      // (no more links are made: the chains only get shorter)
+        stA(parent + i, r);
+        atomicMax(last + r, i);
+    }
+}
+
+__global__ void __launch_bounds__(64) k5c_turns(FsqRow* __restrict__ rows, const int* __restrict__ counts, const int* __restrict__ offsets,
+                                                int H, int W, int radius, int* __restrict__ ws, long long stride)
+{
+    const K5Field F = k5_field(rows, counts, offsets, blockIdx.y, H, W, ws, stride);
+    const int lane = threadIdx.x, rw = radius + 2;
+    const double rr = (double)(radius * radius);
+    const FsqRow* R = F.R;
+    int* grid = F.grid;
+    for (int cbase = blockIdx.x * 64; cbase < F.cnt; cbase += gridDim.x * 64) {
+        const int ci = cbase + lane;
+        unsigned long long roots = __ballot(ci < F.cnt && F.parent[ci] == ci);
+        while (roots) {
+            const int root = cbase + __ffsll((long long)roots) - 1;
+            roots &= roots - 1;
+            const int last = F.last[root];
+            if (last == root) continue;                         // a component of one: its turn finds no rival (the common case)
+            for (int mb = root & ~63; mb <= last; mb += 64) {   // the members, in raster order
+                const int mj = mb + lane;
+                int m_h = 0, m_w = 0;
+                double m_h0 = 0., m_w0 = 0., m_r2 = 0.;
+                bool mem = false;
+                if (mj >= root && mj <= last && F.parent[mj] == root) {
+                    mem = true;
+                    m_h = R[mj].h; m_w = R[mj].w; m_h0 = R[mj].h0; m_w0 = R[mj].w0; m_r2 = R[mj].r2;
+                }
+                unsigned long long mm = __ballot(mem);
+                while (mm) {
+                    const int src = __ffsll((long long)mm) - 1;
+                    mm &= mm - 1;
+                    const int i = mb + src, h = __shfl(m_h, src), w = __shfl(m_w, src);
+                    const double h0 = __shfl(m_h0, src), w0 = __shfl(m_w0, src), r2i = __shfl(m_r2, src);
+                    if (ld_shared_i(&grid[(size_t)h * W + w]) != i) continue;      // deleted by an earlier member
+                    const int h_lo = max(0, h - rw), h_hi = min(h + rw + 1, H), w_lo = max(0, w - rw), w_hi = min(w + rw + 1, W);
+                    const int ww = w_hi - w_lo, ncell = (h_hi - h_lo) * ww;
+                    bool dead = false;
+                    constexpr int NGW = 3;
+                    for (int base = 0; base < ncell && !dead; base += 64 * NGW) {
+                        int kk[NGW];
+                        double rh0[NGW], rw0[NGW], rr2[NGW];
+#pragma unroll
+                        for (int g = 0; g < NGW; g++) {
+                            const int c = base + 64 * g + lane;
+                            kk[g] = -1;
+                            if (c < ncell) {
+                                const int hd = h_lo + c / ww, wd = w_lo + c % ww;
+                                if (!(hd == h && wd == w)) kk[g] = ld_shared_i(&grid[(size_t)hd * W + wd]);
+                            }
+                        }
+#pragma unroll
+                        for (int g = 0; g < NGW; g++) {
+                            const int k = kk[g] >= 0 ? kk[g] : i;
+                            rh0[g] = R[k].h0; rw0[g] = R[k].w0; rr2[g] = R[k].r2;
+                        }
+#pragma unroll
+                        for (int g = 0; g < NGW; g++) {
+                            if (dead || base + 64 * g >= ncell) continue;       // (wave-uniform)
+                            const int c = base + 64 * g + lane;
+                            bool rival = false, lose = false;
+                            if (kk[g] >= 0) {
+                                const double dh = h0 - rh0[g], dw = w0 - rw0[g];
+                                if (!(fsq_pow2(dh) + fsq_pow2(dw) > rr)) {       // numpy scalar **2, pflib.py:505
+                                    rival = true;
+                                    lose = !(r2i > rr2[g]);                     // pflib.py:508
+                                }
+                            }
+                            const unsigned long long mlose = __ballot(lose);
+                            const int first = mlose ? (__ffsll((long long)mlose) - 1) : 64;
+                            if (rival && lane < first) st_shared_i(&grid[(size_t)(h_lo + c / ww) * W + (w_lo + c % ww)], -(kk[g] + 2));
+                            if (mlose) {
+                                if (lane == 0) st_shared_i(&grid[(size_t)h * W + w], -(i + 2));
+                                dead = true;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // this turn's deletions before the next member's reads
+                }
+            }
+        }
+    }
+}
+
+// re-key + kept list (pflib.py:514-519): one block per field - the tail of the block kernel above, over all candidates
+__global__ void __launch_bounds__(512) k5c_finish(FsqRow* __restrict__ rows, const int* __restrict__ counts, const int* __restrict__ offsets,
+                                                  int H, int W, int py2, int* __restrict__ ws, long long stride, int* __restrict__ chunk_all,
+                                                  long long chunk_stride, int* __restrict__ keep, int* __restrict__ nkeep)
+{
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const K5Field F = k5_field(rows, counts, offsets, f, H, W, ws, stride);
+    FsqRow* R = F.R;
+    int* grid = F.grid;
+    const int cnt = F.cnt, off = F.off;
+    int* chunkc = chunk_all + (size_t)f * chunk_stride;
+    __shared__ int s_total, s_assert;
+    if (tid == 0) s_assert = 0;
+    __syncthreads();
+    auto key_of = [&](int i, int* hr, int* wr) { *hr = (int)round_key(R[i].h0, py2); *wr = (int)round_key(R[i].w0, py2); };
+    for (int i = tid; i < cnt; i += blockDim.x) {
+        if (F.parent[i] < 0 || grid[(size_t)R[i].h * W + R[i].w] != i) continue;     // not a survivor / deleted
+        int hr, wr;
+        key_of(i, &hr, &wr);
+        R[i].key_h = hr; R[i].key_w = wr;
+        if ((hr != R[i].h || wr != R[i].w) && hr >= 0 && hr < H && wr >= 0 && wr < W) {
+            const int j = grid[(size_t)hr * W + wr];
+            if (j >= 0) {
+                int hj, wj;
+                key_of(j, &hj, &wj);
+                if (!(j < i && (hj != R[j].h || wj != R[j].w))) s_assert = 1;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
+    for (int i = tid; i < cnt; i += blockDim.x)
+        if (R[i].key_h >= 0 && (R[i].key_h != R[i].h || R[i].key_w != R[i].w)) grid[(size_t)R[i].h * W + R[i].w] = -1;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
+    for (int i = tid; i < cnt; i += blockDim.x) {
+        const int hr = R[i].key_h, wr = R[i].key_w;
+        if (hr >= 0 && (hr != R[i].h || wr != R[i].w) && hr < H && wr >= 0 && wr < W)
+            if (atomicExch(&grid[(size_t)hr * W + wr], i) >= 0) s_assert = 1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
+    const int nk0 = block_compact(cnt, chunkc, keep, off, [&](int i) { return R[i].key_h >= 0 && R[i].key_h == R[i].h && R[i].key_w == R[i].w; },
+                                  [&](int i) { return off + i; }, &s_total);
+    const int nk1 = block_compact(cnt, chunkc, keep, off + nk0, [&](int i) { return R[i].key_h >= 0 && (R[i].key_h != R[i].h || R[i].key_w != R[i].w); },
+                                  [&](int i) { return off + i; }, &s_total);
+    if (tid == 0) nkeep[f] = s_assert ? -1 : nk0 + nk1;
+}
+
 __global__ void k5_total(int* __restrict__ nkeep, int n_fields)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -351,13 +605,13 @@ extern "C" int fsq_kept_rows(const FsqRow* d_rows, const int32_t* d_keep, const 
     return FSQ_OK;
 }
 
-// per field: the pixel -> candidate grid (int32 per pixel), a turn flag per candidate (at most one candidate per pixel) and
-// the chunk counters of the ordered compactions (one per 64 candidates)
+// per field: the pixel -> candidate grid, the union-find parents and the components' last members (int32 per pixel each: there is at
+// most one candidate per pixel), and the chunk counters of the ordered compactions (one per 64 candidates)
 static int64_t k5_chunk_stride(int H, int W) { return ((int64_t)H * W + 63) / 64 + 2; }
 extern "C" int64_t fsq_consolidate_workspace_bytes(int n_fields, int H, int W)
 {
     if (n_fields < 1 || H < 1 || W < 1) return FSQ_EINVAL;
-    return (int64_t)n_fields * ((int64_t)H * W * 5 + k5_chunk_stride(H, W) * 4) + 256;
+    return (int64_t)n_fields * ((int64_t)H * W * 12 + k5_chunk_stride(H, W) * 4) + 256;
 }
 
 extern "C" int fsq_consolidate(FsqRow* d_rows, const int32_t* d_counts, const int32_t* d_offsets, int n_fields, int H,
@@ -368,15 +622,39 @@ extern "C" int fsq_consolidate(FsqRow* d_rows, const int32_t* d_counts, const in
     if (n_fields < 1 || H < 5 || W < 5 || !d_rows || !d_counts || !d_offsets || !d_keep || !d_nkeep || !d_workspace) return FSQ_EINVAL;
     if (workspace_bytes < fsq_consolidate_workspace_bytes(n_fields, H, W)) return FSQ_ENOMEM;
     hipStream_t s = (hipStream_t)stream;
-    const size_t px = (size_t)n_fields * H * W;
-    int* grid = (int*)d_workspace;
-    unsigned char* turn = (unsigned char*)d_workspace + px * 4;
-    int* chunks = (int*)((unsigned char*)d_workspace + ((px * 5 + 255) & ~(size_t)255));
-    FSQ_HIP_CHECK(hipMemsetAsync(d_workspace, 0xFF, px * 4, s));
-    // 16 waves per field for large fields (thousands of survivors to take turns), 8 otherwise
-    const int threads = ((int64_t)H * W > (1 << 20)) ? 1024 : 512;
-    hipLaunchKernelGGL(k5_consolidate, dim3(n_fields), dim3(threads), 0, s, d_rows, d_counts, d_offsets, H, W, r2_threshold,
-                       radius, py2_round, grid, turn, chunks, (long long)k5_chunk_stride(H, W), d_keep, d_nkeep);
+    const size_t px = (size_t)H * W;
+    int* ws = (int*)d_workspace;
+    const long long stride = 3 * (long long)px;                       // ints per field: grid | parent | last
+    int* chunks = ws + (size_t)n_fields * stride;
+    // Which form: both give the same tables.  The components form spreads a field over the whole chip; once the FIELDS alone fill
+    // it (1 024 fields of 512^2: 8 waves each) the block form, which scans a neighbourhood only when a candidate has to wait, is the
+    // cheaper one (measured, tools/r04_consol2.sh: 4.0 against 4.6 ms for 1 024 fields of 512^2; 9.7 against 2.1 ms for 32 fields of
+    // 2 048^2; 1.27 against 0.50 ms for 64 fields of 512^2).  FSQ_CONSOLIDATE_BLOCKS / FSQ_CONSOLIDATE_COMPONENTS force one.
+    const int block_threads = ((int64_t)H * W > (1 << 20)) ? 1024 : 512;
+    bool blocks = (long long)n_fields * (block_threads / 64) >= 8192;
+    if (getenv("FSQ_CONSOLIDATE_BLOCKS")) blocks = true;
+    if (getenv("FSQ_CONSOLIDATE_COMPONENTS")) blocks = false;
+    if (blocks) {
+        // round 4's first form: one block of 8 / 16 waves per field taking the turns by dependency (see k5_consolidate)
+        int* grid = ws;
+        unsigned char* turn = (unsigned char*)(ws + (size_t)n_fields * px);
+        int* chunks_b = ws + (size_t)n_fields * 2 * px;
+        FSQ_HIP_CHECK(hipMemsetAsync(grid, 0xFF, (size_t)n_fields * px * 4, s));
+        hipLaunchKernelGGL(k5_consolidate, dim3(n_fields), dim3(block_threads), 0, s, d_rows, d_counts, d_offsets, H, W, r2_threshold,
+                           radius, py2_round, grid, turn, chunks_b, (long long)k5_chunk_stride(H, W), d_keep, d_nkeep);
+    } else {
+        // (only the grids have to be -1: one strided memset over the fields' [grid | parent | last] blocks)
+        FSQ_HIP_CHECK(hipMemset2DAsync(ws, (size_t)stride * 4, 0xFF, px * 4, n_fields, s));
+        // blocks (of one wave) per field: enough waves to fill the chip whatever the number of fields, each taking 64 candidates at a time
+        const int bpf = (int)std::max<long long>(8, std::min<long long>(((long long)px + 63) / 64, 16384 / n_fields));
+        const dim3 g(bpf, n_fields);
+        hipLaunchKernelGGL(k5c_insert, g, dim3(64), 0, s, d_rows, d_counts, d_offsets, H, W, r2_threshold, ws, stride);
+        hipLaunchKernelGGL(k5c_union, g, dim3(64), 0, s, d_rows, d_counts, d_offsets, H, W, radius, ws, stride);
+        hipLaunchKernelGGL(k5c_flatten, g, dim3(64), 0, s, d_counts, d_offsets, H, W, ws, stride);
+        hipLaunchKernelGGL(k5c_turns, g, dim3(64), 0, s, d_rows, d_counts, d_offsets, H, W, radius, ws, stride);
+        hipLaunchKernelGGL(k5c_finish, dim3(n_fields), dim3(512), 0, s, d_rows, d_counts, d_offsets, H, W, py2_round, ws, stride, chunks,
+                           (long long)k5_chunk_stride(H, W), d_keep, d_nkeep);
+    }
     hipLaunchKernelGGL(k5_total, dim3(1), dim3(1), 0, s, d_nkeep, n_fields);
     FSQ_HIP_CHECK(hipGetLastError());
     return FSQ_OK;

@@ -3,7 +3,7 @@ R^2 filter, consolidation, re-key with its assert) restated in Python, against t
 block take the candidates' turns concurrently wherever the windows do not interact.  The tables are made to interact as much as
 possible: up to every pixel a survivor, long chains of overlapping windows, exact R^2 ties, NaN R^2 (passes the filter, loses every
 comparison), fitted centres half a pixel off (re-keys, colliding re-keys: the reference's AssertionError), radii 2 .. 9 (windows
-larger than the one-pass register window), fields of one block's 8 and 16 waves."""
+larger than the one-pass register window), fields of one block's 8 and 16 waves - in both of the kernel's schedules."""
 import numpy as np
 import pytest
 
@@ -73,9 +73,13 @@ def make_field(rng, H, W, kind):
     return h.astype(np.int32), w.astype(np.int32), h0, w0, r2
 
 
+@pytest.mark.parametrize("form", ["components", "blocks"])
 @pytest.mark.parametrize("H,W,radius", [(40, 56, 4), (33, 47, 2), (64, 64, 7), (48, 40, 9), (1100, 1000, 4)])
-def test_consolidation_equals_the_sequential_reference(H, W, radius):
+def test_consolidation_equals_the_sequential_reference(H, W, radius, form, monkeypatch):
+    """form: the kernel's two schedules (csrc/fsq_consolidate.hip) - connected components of overlapping windows, each walked by one
+    wave, and one block per field whose waves take turns by dependency; the library picks one by the batch's shape, here each is forced."""
     import torch
+    monkeypatch.setenv("FSQ_CONSOLIDATE_" + form.upper(), "1")
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     from fluorosequencingimageanalysis_amd import _native as N, engine as E
     rng = np.random.default_rng(1000 * H + radius)
