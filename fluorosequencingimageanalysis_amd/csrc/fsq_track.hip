@@ -17,7 +17,8 @@
 
 namespace {
 
-constexpr int TRK_SMAX = 32768;         // spots of one field (all frames) at most
+constexpr int TRK_SMAX = 32768;         // up to this many spots per field (all frames) the "has been paired" flags are bitmaps in LDS;
+                                        // larger fields read the links themselves (round 4: no spot limit)
 constexpr int TRK_FLDS = 64;            // frame tables (cumulative offsets, first spot of every frame) of up to this many frames live
                                         // in LDS; longer time series keep them in the caller's workspace (round 4: no frame limit)
 
@@ -34,6 +35,7 @@ struct TrkShared {
     unsigned a_taken[TRK_SMAX / 32], d_taken[TRK_SMAX / 32];
     double cum[TRK_FLDS][2];
     int fs[TRK_FLDS + 1];
+    int hc[TRK_FLDS];                   // heads (trace starts) per frame
     int np, ndisc, status, nheads;
 };
 
@@ -63,15 +65,17 @@ __global__ void __launch_bounds__(256) k8_track(const int32_t* __restrict__ hw, 
     int32_t* my_next = next + s0;
     uint8_t* my_kept = kept + s0;
     // frame tables: cum[f] = the offsets accumulated up to frame f, fs[f] = number of the first spot of frame f
-    double* cum = (F <= TRK_FLDS) ? &S.cum[0][0] : frame_ws + (size_t)fld * ((size_t)F * 2 + (size_t)(F + 2) / 2 + 1);
+    double* cum = (F <= TRK_FLDS) ? &S.cum[0][0] : frame_ws + (size_t)fld * ((size_t)F * 2 + (size_t)(F + 2) / 2 + 1 + (size_t)(F + 1) / 2);
     int* fs = (F <= TRK_FLDS) ? S.fs : (int*)(cum + (size_t)F * 2);
+    int* hc = (F <= TRK_FLDS) ? S.hc : (int*)(cum + (size_t)F * 2 + (size_t)(F + 2) / 2 + 1);
+    const bool lds_flags = n <= TRK_SMAX;
     const double* off = offsets + (size_t)fld * F * 2;
     if (t == 0) {
         S.np = 0; S.ndisc = 0; S.status = 0; S.nheads = 0;
         fs[0] = 0;
         for (int f = 0; f < F; f++) fs[f + 1] = fs[f] + counts[(size_t)fld * F + f];
         if (off[0] != 0.0 || off[1] != 0.0) S.status = FSQ_EINVAL;          // ValueError, flexlibrary.py:581-583
-        if (fs[F] != n || n > TRK_SMAX) S.status = FSQ_EINVAL;
+        if (fs[F] != n) S.status = FSQ_EINVAL;
     }
     for (int f = t; f < F; f += 256) {                  // accumulate_offsets: a fresh left-to-right sum per frame (flexlibrary.py:585-600)
         double sh = 0.0, sw = 0.0;
@@ -173,10 +177,12 @@ __global__ void __launch_bounds__(256) k8_track(const int32_t* __restrict__ hw, 
         if (t == 0) {                                                   // greedy acceptance in sorted order
             for (int k = 0; k < np; k++) {
                 const int i = P.order[k], a = P.a_spot[i], d = P.d_spot[i];
-                if ((S.a_taken[a >> 5] >> (a & 31)) & 1u) continue;     // ancestor has been paired
-                if ((S.d_taken[d >> 5] >> (d & 31)) & 1u) continue;     // descendant has been paired
-                S.a_taken[a >> 5] |= 1u << (a & 31);
-                S.d_taken[d >> 5] |= 1u << (d & 31);
+                if (lds_flags) {
+                    if ((S.a_taken[a >> 5] >> (a & 31)) & 1u) continue;     // ancestor has been paired
+                    if ((S.d_taken[d >> 5] >> (d & 31)) & 1u) continue;     // descendant has been paired
+                    S.a_taken[a >> 5] |= 1u << (a & 31);
+                    S.d_taken[d >> 5] |= 1u << (d & 31);
+                } else if (my_next[a] != -1 || my_prev[d] != -1) continue;   // (the same two facts, read off the links this thread writes)
                 my_prev[d] = a; my_next[a] = d;
                 cache[(unsigned)(P.key2[i] >> 32)] = -1;
             }
@@ -189,20 +195,27 @@ __global__ void __launch_bounds__(256) k8_track(const int32_t* __restrict__ hw, 
         if (my_kept[i]) cache[cell_of(i, frame_of(i))] = -1;
     // ---- traces: heads by (frame, bin), each followed along its links (flexlibrary.py:975-1026) -------------------
     int32_t* my_traces = traces + (size_t)s0 * F;
+    // a head's row = the heads of earlier frames + the heads of its own frame in smaller bins
+    for (int f = t; f < F; f += 256) hc[f] = 0;
+    __syncthreads();
+    for (int i = t; i < n; i += 256)
+        if (my_kept[i] && my_prev[i] == -1) atomicAdd(&hc[frame_of(i)], 1);
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int f = 0; f < F; f++) { const int c_ = hc[f]; hc[f] = run; run += c_; }
+        S.nheads = run;
+    }
+    __syncthreads();
     for (int i = t; i < n; i += 256) {
         if (!my_kept[i] || my_prev[i] != -1) continue;
-        const int f = frame_of(i);
-        const unsigned long long key = (unsigned long long)f * cells + (unsigned)cell_of(i, f);
-        int r = 0;
-        for (int j = 0; j < n; j++) {
-            if (!my_kept[j] || my_prev[j] != -1) continue;
-            const int fj = frame_of(j);
-            r += ((unsigned long long)fj * cells + (unsigned)cell_of(j, fj)) < key;
-        }
+        const int f = frame_of(i), cell = cell_of(i, f);
+        int r = hc[f];
+        for (int j = fs[f]; j < fs[f + 1]; j++)
+            r += (my_kept[j] && my_prev[j] == -1 && cell_of(j, f) < cell);
         int32_t* row = my_traces + (size_t)r * F;
         for (int g = 0; g < F; g++) row[g] = -1;
         for (int c = i; c != -1; c = my_next[c]) row[frame_of(c)] = c;
-        atomicAdd(&S.nheads, 1);
     }
     __syncthreads();
     if (t == 0) { status_out[fld] = 0; n_traces[fld] = S.nheads; n_disc[fld] = S.ndisc; }
@@ -297,7 +310,7 @@ __global__ void kx87check(const double* __restrict__ dh, const double* __restric
 }  // namespace
 
 // per field: two bin grids, the candidate-pair list of one frame, and - for time series of more than TRK_FLDS frames - the frame tables
-static int64_t trk_frame_doubles(int n_frames) { return n_frames <= TRK_FLDS ? 0 : (int64_t)n_frames * 2 + ((int64_t)n_frames + 2) / 2 + 1; }
+static int64_t trk_frame_doubles(int n_frames) { return n_frames <= TRK_FLDS ? 0 : (int64_t)n_frames * 2 + ((int64_t)n_frames + 2) / 2 + 1 + ((int64_t)n_frames + 1) / 2; }
 extern "C" int64_t fsq_track_workspace_bytes(int n_fields, int n_frames, int H, int W, int64_t pair_cap)
 {
     if (n_fields < 1 || n_frames < 1 || H < 1 || W < 1 || pair_cap < 1) return FSQ_EINVAL;

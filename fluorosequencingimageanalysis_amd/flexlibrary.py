@@ -50,11 +50,8 @@ def track_fields(fields, offsets, frame_shape, candidate_radius=2, spot_radius=0
     hw = np.ascontiguousarray(np.concatenate(parts) if parts else np.zeros((0, 2), np.int32))
     start = np.concatenate([[0], np.cumsum(counts.sum(axis=1))]).astype(np.int32)
     total = int(start[-1])
-    # the kernel's limit (csrc/fsq_track.hip: one block walks a field with its spot flags in LDS); the reference has none.
-    # (The number of frames is unlimited since round 4: the frame tables of long time series live in the workspace.)
-    if counts.size and int(counts.sum(axis=1).max()) > TRACK_MAX_SPOTS:
-        raise NotImplementedError("greedy tracking on the GPU handles at most %d spots per field, all frames together (got %d)"
-                                  % (TRACK_MAX_SPOTS, int(counts.sum(axis=1).max())))
+    # (no limit on frames or spots since round 4: long time series keep their frame tables in the workspace, large fields read the
+    # "has been paired" facts off the links instead of LDS bitmaps; the reference has no limit either)
     off = np.ascontiguousarray(np.array([[(float(o[0]), float(o[1])) for o in offs] for offs in offsets], dtype=np.float64))
     for k in range(n_fields):
         if off[k, 0, 0] != 0 or off[k, 0, 1] != 0:
@@ -78,7 +75,6 @@ def track_fields(fields, offsets, frame_shape, candidate_radius=2, spot_radius=0
     return out
 
 
-TRACK_MAX_SPOTS = 32768
 
 
 def _track_launch(torch, dev, L, hw, start, counts, off, n_fields, F, H, W, candidate_radius, spot_radius, pair_cap, total):

@@ -266,8 +266,8 @@ int fsq_mexican_hat(const uint16_t* d_img, int n_fields, int H, int W, const int
  *                                    ValueError), FSQ_EASSERT (two spots of a frame in one bin: its AssertionError,
  *                                    flexlibrary.py:851), FSQ_ERANGE (more than pair_cap candidate pairs in one frame)
  *   pair_cap       capacity of the per-frame candidate-pair list (a few times the spots per frame)
- * At most 32 768 spots per field (all frames together); any number of frames (time series of more than 64 frames keep their
- * frame tables in the workspace).  Enqueue only.
+ * Any number of frames and spots (time series of more than 64 frames keep their frame tables in the workspace; fields of more
+ * than 32 768 spots read the pairing facts off the links instead of LDS bitmaps).  Enqueue only.
  */
 int64_t fsq_track_workspace_bytes(int n_fields, int n_frames, int H, int W, int64_t pair_cap);
 int fsq_greedy_tracking(const int32_t* d_hw, const int32_t* d_field_start, const int32_t* d_counts, const double* d_offsets,

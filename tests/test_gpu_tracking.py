@@ -87,10 +87,19 @@ def test_tracking_errors(env):
         fl.Experiment.accumulate_offsets([(0, 1), (0, 0)])
     with pytest.raises(TypeError):
         fl.Experiment.greedy_particle_tracking([[]], (8, 8))
-    # the kernel's limit is named (the reference has none): 32 768 spots per field
-    lattice = np.array([(h, w) for h in range(182) for w in range(182)], np.int32)          # 33 124 spots in one frame
-    with pytest.raises(NotImplementedError, match="32768 spots"):
-        fl.track_fields([[lattice]], [[(0, 0)]], (200, 200))
+
+
+def test_large_fields_equal_the_oracle(env):
+    """More than 32 768 spots in one field (the LDS pairing bitmaps end there; round 4 reads the pairing facts off the links): a
+    lattice of 182 x 182 = 33 124 spots per frame moving by one pixel over three frames (99 372 spots) against the oracle tracker."""
+    torch, N, fl, O = env
+    lattice = np.array([(h, w) for h in range(8, 372, 2) for w in range(8, 372, 2)], np.int32)          # 33 124 spots, 2 px apart
+    frames = [lattice, lattice + np.array([0, 1], np.int32), lattice + np.array([1, 1], np.int32)]
+    offsets = [(0, 0), (0, 0), (0, 0)]
+    got, nd, prev, nxt, kept = fl.track_fields([frames], [offsets], (384, 384), candidate_radius=2)[0]
+    o_tr, o_nd, o_prev, o_next, o_kept = O.greedy_tracking(frames, offsets, (384, 384), 2, 0)
+    assert len(lattice) > 32768 and nd == o_nd and np.array_equal(kept, o_kept)
+    assert np.array_equal(prev, o_prev) and np.array_equal(nxt, o_next) and np.array_equal(got, o_tr)
 
 
 def test_long_time_series_equal_the_oracle(env):
