@@ -22,9 +22,12 @@ ROW_DTYPE = np.dtype([(k, np.float64) for k in
 assert ROW_DTYPE.itemsize == 128
 
 
+MAX_KSIZE = 15              # FSQ_MAX_KSIZE of include/fsq.h
+
+
 class FsqDetectParams(ctypes.Structure):
     _fields_ = [("median_filter_size", ctypes.c_int32), ("ksz", ctypes.c_int32), ("c_std", ctypes.c_double),
-                ("K", ctypes.c_int64 * 81), ("pixel_format", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("K", ctypes.c_int64 * (MAX_KSIZE * MAX_KSIZE)), ("pixel_format", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class NativeLibraryMissing(RuntimeError):

@@ -3,7 +3,7 @@
 
 thread_local hipError_t g_fsq_last_hip = hipSuccess;
 
-extern "C" const char* fsq_version(void) { return "fsq-hip 0.1 (gfx950)"; }
+extern "C" const char* fsq_version(void) { return "fsq-hip 0.4 (gfx950)"; }
 extern "C" const char* fsq_last_hip_error(void) { return hipGetErrorString(g_fsq_last_hip); }
 extern "C" int fsq_device_count(void)
 {

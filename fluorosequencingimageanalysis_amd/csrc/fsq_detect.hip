@@ -23,7 +23,7 @@ namespace {
 #include "fsq_median_net.h"
 
 constexpr int TW = 64, TH = 16;          // output tile of k1 (1024 px, 256 threads x 4 px)
-constexpr int MAXK = 9;                  // largest correlation matrix / median window side
+constexpr int MAXK = FSQ_MAX_KSIZE;      // largest correlation matrix / median window side
 constexpr int CHUNK = 8192;              // numpy ufunc buffer size in elements (NPY_BUFSIZE)
 
 struct DetectConst {
@@ -565,7 +565,7 @@ extern "C" int fsq_detect(const uint16_t* d_img, int n_fields, int H, int W, con
         const int MH = TH + 2 * kc, MW = TW + 2 * kc, RH = MH + mo + me, RW = MW + mo + me;
         size_t shm = (((size_t)RH * RW * 2 + 15) & ~(size_t)15) + (size_t)MH * MW * 4;
         dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, n_fields);
-        if (med == 5 && !getenv("FSQ_DETECT_R03")) {
+        if (med == 5 && ksz <= 9 && !getenv("FSQ_DETECT_R03")) {
             // a correlation matrix whose entries depend on the ring only (the default one) needs three multiplications per pixel
             bool ring = (ksz == 5);
             for (int a = 0; a < 5 && ring; a++)

@@ -78,18 +78,68 @@ __global__ void __launch_bounds__(256) k7_mexican_hat(const uint16_t* __restrict
     if (lane == 0) out[spot] = (double)crown - (double)ncrown * med;
 }
 
+// Any radius (round 4: the register form above holds 31 x 31 windows; the reference has no limit, flexlibrary.py:172-210): the
+// same arithmetic with the window re-read from memory (it stays in L1 / L2) for every step of the binary search.
+__global__ void __launch_bounds__(256) k7_mexican_hat_any(const uint16_t* __restrict__ img, int H, int W,
+                                                           const int32_t* __restrict__ fhw, long long n, int brim, int radius,
+                                                           double* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const long long spot = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (spot >= n) return;
+    const int f = fhw[3 * spot], h = fhw[3 * spot + 1], w = fhw[3 * spot + 2];
+    const int r0 = max(0, h - radius), r1 = min(H, h + radius + 1);
+    const int c0 = max(0, w - radius), c1 = min(W, w + radius + 1);
+    const int hc = max(r1 - r0, 0), wc = max(c1 - c0, 0), npx = hc * wc, diameter = 2 * radius + 1;
+    const uint16_t* base = img + ((size_t)f * H) * W;
+    auto in_crown = [&](int hh, int ww) { return (brim <= hh) && (hh < diameter - brim) && (brim <= ww) && (ww < diameter - brim); };
+    long long crown = 0;
+    int ncrown = 0, nbrim = 0;
+    for (int i = lane; i < npx; i += 64) {
+        const int hh = i / wc, ww = i - hh * wc;
+        const unsigned p = base[(size_t)(r0 + hh) * W + (c0 + ww)];
+        if (in_crown(hh, ww)) { crown += p; ncrown++; } else nbrim++;
+    }
+    crown = wave_sum_ll(crown);
+    ncrown = wave_sum_i(ncrown);
+    nbrim = wave_sum_i(nbrim);
+    auto kth = [&](int rank) {           // smallest value x with #{brim <= x} >= rank + 1
+        unsigned lo = 0, hi = 65535;
+        for (int it = 0; it < 16; it++) {
+            const unsigned mid = (lo + hi) >> 1;
+            int c = 0;
+            for (int i = lane; i < npx; i += 64) {
+                const int hh = i / wc, ww = i - hh * wc;
+                if (!in_crown(hh, ww)) c += ((unsigned)base[(size_t)(r0 + hh) * W + (c0 + ww)] <= mid);
+            }
+            c = wave_sum_i(c);
+            if (c >= rank + 1) hi = mid; else lo = mid + 1;
+        }
+        return lo;
+    };
+    double med;
+    if (nbrim == 0) med = __builtin_nan("");
+    else if (nbrim & 1) med = (double)kth(nbrim / 2);
+    else med = ((double)kth(nbrim / 2 - 1) + (double)kth(nbrim / 2)) / 2.0;
+    if (lane == 0) out[spot] = (double)crown - (double)ncrown * med;
+}
+
 }  // namespace
 
 extern "C" int fsq_mexican_hat(const uint16_t* d_img, int n_fields, int H, int W, const int32_t* d_fhw, int64_t n,
                                int brim_size, int radius, double* d_out, void* stream)
 {
     if (n < 0 || n_fields < 1 || H < 1 || W < 1 || brim_size < 0 || radius < 0) return FSQ_EINVAL;
-    if (radius > MAXR) return FSQ_ENOTIMPL;
+    if (radius > 16383) return FSQ_EINVAL;                        // ((2 r + 1)^2 must fit an int)
     if (n == 0) return FSQ_OK;
     if (!d_img || !d_fhw || !d_out) return FSQ_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k7_mexican_hat, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, d_img, H, W, d_fhw, (long long)n,
-                       brim_size, radius, d_out);
+    if (radius <= MAXR)
+        hipLaunchKernelGGL(k7_mexican_hat, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, d_img, H, W, d_fhw, (long long)n,
+                           brim_size, radius, d_out);
+    else
+        hipLaunchKernelGGL(k7_mexican_hat_any, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, d_img, H, W, d_fhw, (long long)n,
+                           brim_size, radius, d_out);
     FSQ_HIP_CHECK(hipGetLastError());
     return FSQ_OK;
 }

@@ -81,8 +81,8 @@ def detect_params(median_filter_size, correlation_matrix, c_std, pixel_format=N.
     K = np.asarray(correlation_matrix)
     if K.ndim != 2 or K.shape[0] != K.shape[1] or K.shape[0] % 2 == 0:
         raise ValueError("correlation_matrix must be square, with an odd number of rows and columns")
-    if K.shape[0] > 9 or not (1 <= int(median_filter_size) <= 9):
-        raise NotImplementedError("correlation_matrix / median_filter_size larger than 9 are not supported")
+    if K.shape[0] > N.MAX_KSIZE or not (1 <= int(median_filter_size) <= N.MAX_KSIZE):
+        raise NotImplementedError("correlation_matrix / median_filter_size larger than %d are not supported" % N.MAX_KSIZE)
     p = N.FsqDetectParams()
     p.median_filter_size = int(median_filter_size)
     p.ksz = int(K.shape[0])

@@ -70,11 +70,12 @@ typedef struct FsqRow {
 #define FSQ_PIXELS_U16 0
 #define FSQ_PIXELS_F16 1
 
+#define FSQ_MAX_KSIZE 15                           /* largest correlation matrix / median window side (round 4: was 9) */
 typedef struct FsqDetectParams {
-    int32_t median_filter_size;                     /* pflib default 5 */
-    int32_t ksz;                                    /* correlation_matrix side, odd */
+    int32_t median_filter_size;                     /* pflib default 5; 1 .. FSQ_MAX_KSIZE */
+    int32_t ksz;                                    /* correlation_matrix side, odd, <= FSQ_MAX_KSIZE */
     double c_std;                                   /* pflib default 2 */
-    int64_t K[81];                                  /* correlation_matrix, row-major, ksz <= 9 */
+    int64_t K[FSQ_MAX_KSIZE * FSQ_MAX_KSIZE];       /* correlation_matrix, row-major (ksz * ksz entries used) */
     int32_t pixel_format;                           /* FSQ_PIXELS_U16 / FSQ_PIXELS_F16 of d_img */
     int32_t reserved;
 } FsqDetectParams;
@@ -240,7 +241,7 @@ int fsq_phase_correlate(const void* d_ref, const void* d_reg, int dtype, int n_p
  *   d_img   uint16[n_fields][H][W]; d_fhw int32[n][3] = (field, h, w) integer spot centres (the caller guarantees
  *           0 <= field < n_fields; h, w may lie anywhere - the window is clipped like Spot.image_slice,
  *           flexlibrary.py:140-146, and an empty brim gives nan like numpy.median([]))
- *   d_out   double[n]: sum(crown) - len(crown) * median(brim); radius <= 15 (FSQ_ENOTIMPL beyond)
+ *   d_out   double[n]: sum(crown) - len(crown) * median(brim); any radius (windows beyond 31 x 31 are re-read per median step)
  * Enqueues on the stream, does not synchronise.
  */
 int fsq_mexican_hat(const uint16_t* d_img, int n_fields, int H, int W, const int32_t* d_fhw, int64_t n,

@@ -87,6 +87,24 @@ def test_nondefault_parameters(env):
         assert bits_equal(got, exp).all()
 
 
+def test_large_windows(env):
+    """Median windows and correlation matrices beyond 9 x 9 (the limit until round 4; now FSQ_MAX_KSIZE = 15): candidates equal to
+    the oracle's, and the size beyond the limit is refused with a message that names it."""
+    torch, pflib, engine, O = env
+    g, img = load_field("f5_small_96")
+    rng = np.random.default_rng(15)
+    for med, ks in ((11, 13), (15, 15), (5, 11), (12, 3)):
+        KK = rng.integers(-5, 6, (ks, ks)).astype(np.int64)
+        KK[ks // 2, ks // 2] += 40
+        cand = pflib._psf_candidates(img, median_filter_size=med, correlation_matrix=KK, c_std=1.5)
+        ref = O.candidates(img, med_size=med, K=KK, c_std=1.5)
+        assert len(ref) > 0 and cand == [tuple(int(v) for v in hw) for hw in ref]
+    with pytest.raises(NotImplementedError, match="15"):
+        pflib._psf_candidates(img, median_filter_size=5, correlation_matrix=np.ones((17, 17), np.int64))
+    with pytest.raises(NotImplementedError, match="15"):
+        pflib._psf_candidates(img, median_filter_size=16)
+
+
 def test_edge_cases(env):
     torch, pflib, engine, O = env
     # empty: a flat image has no candidates above threshold... (cm all zero -> thr 0 -> every interior pixel passes)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off fuzz of the detection stage (fsq_detect behind pflib._psf_candidates) against the oracle (TEST TOOL): random image
-shapes from 5x5 up, every median size 1..9 (even ones too: scipy's origin convention), random integer correlation matrices of
-1x1 .. 9x9 with negative entries, c_std incl. 0 and negative, noise / sparse / saturated / constant images, batches of several
+shapes from 5x5 up, every median size 1..15 (even ones too: scipy's origin convention), random integer correlation matrices of
+1x1 .. 15x15 with negative entries, c_std incl. 0 and negative, noise / sparse / saturated / constant images, batches of several
 fields.  The oracle itself was checked against scipy.ndimage.median_filter + scipy.signal.correlate on the same kind of input
 (300 random cases, 0 differences).   usage: python3 tools/fuzz_detect.py [seed] [cases]"""
 import os
@@ -34,8 +34,8 @@ for t in range(cases):
     else:
         imgs = rng.integers(60000, 65536, (nf, H, W))
     imgs = imgs.astype(np.uint16)
-    m = int(rng.integers(1, 10))
-    ks = int(rng.choice([1, 3, 5, 7, 9]))
+    m = int(rng.integers(1, 16)) if rng.random() < 0.3 else int(rng.integers(1, 10))       # (1 .. FSQ_MAX_KSIZE = 15; the large ones are slow)
+    ks = int(rng.choice([1, 3, 5, 7, 9, 11, 13, 15]))
     K = rng.integers(-6, 7, (ks, ks)).astype(np.int64) if rng.random() < 0.8 else pflib.default_correlation_matrix
     c = float(rng.choice([0.0, 0.5, 1.0, 2.0, 3.5, -1.0]))
     prm = E.detect_params(m, K, c)
