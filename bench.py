@@ -74,7 +74,7 @@ def main():
                     help="stream: continuous batching of the LM fits across steps (engine.StreamPipeline); "
                          "lanes: every step a stand-alone batch, worked as --lanes shares (engine.LanePipeline)")
     ap.add_argument("--lanes", type=int, default=2, help="lanes pipeline: shares of the batch worked side by side")
-    ap.add_argument("--queues", type=int, default=2,
+    ap.add_argument("--queues", type=int, default=3,
                     help="stream pipeline: fit queues (each with its own streams and host thread) the fields of every step are "
                          "split over; the kernels of different queues overlap each other's ramp-down")
     ap.add_argument("--depth", type=int, default=16, help="stream pipeline: batches in flight at most")

@@ -21,8 +21,8 @@ def kind(name):
     return "other"
 
 
-for tag, title, steps in (("stats", "python3 bench.py --steps 6 --warmup 1 (the default: two fit queues side by side; 1 + 1 + 6 = 8 steps run). "
-                           "Kernels of the two queues run CONCURRENTLY: their durations overlap and add up to more than wall time", 8),
+for tag, title, steps in (("stats", "python3 bench.py --steps 6 --warmup 1 (the default: three fit queues side by side; 1 + 1 + 6 = 8 steps run). "
+                           "Kernels of the queues run CONCURRENTLY: their durations overlap and add up to more than wall time", 8),
                           ("stats_q1", "python3 bench.py --steps 6 --warmup 1 --queues 1 (one fit queue: kernels run one after the other, "
                            "durations add up to busy time)", 8),
                           ("stats_cfg3", "python3 bench.py --config 3 --steps 10 --warmup 2 (1 + 2 + 10 = 13 registration calls)", 13),
