@@ -14,6 +14,7 @@ FSQ_OK, FSQ_EINVAL, FSQ_ENOMEM, FSQ_ERANGE, FSQ_EHIP, FSQ_EASSERT, FSQ_ENOTIMPL,
 MAX_TICKETS = 32
 MODE_REF, MODE_TEXTBOOK, MODE_TEXTBOOK_F32, ENGINE_LANE, ENGINE_QUAD = 0, 1, 2, 0x100, 0x200
 PIXELS_U16, PIXELS_F16, PIXELS_F16_FLAG = 0, 1, 0x1000
+PIXELS_U32, PIXELS_U32_FLAG = 2, 0x2000        # uint32 pixels (values < 2^31): fsq_detect / fsq_fit_candidates only
 DTYPE_F64, DTYPE_U16 = 0, 1
 
 ROW_DTYPE = np.dtype([(k, np.float64) for k in
@@ -27,7 +28,7 @@ MAX_KSIZE = 15              # FSQ_MAX_KSIZE of include/fsq.h
 
 class FsqDetectParams(ctypes.Structure):
     _fields_ = [("median_filter_size", ctypes.c_int32), ("ksz", ctypes.c_int32), ("c_std", ctypes.c_double),
-                ("K", ctypes.c_int64 * (MAX_KSIZE * MAX_KSIZE)), ("pixel_format", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("K", ctypes.c_int64 * (MAX_KSIZE * MAX_KSIZE)), ("pixel_format", ctypes.c_int32), ("pixel_bits", ctypes.c_int32)]
 
 
 class NativeLibraryMissing(RuntimeError):

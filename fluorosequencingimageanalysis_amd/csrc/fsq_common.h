@@ -17,6 +17,7 @@ extern thread_local hipError_t g_fsq_last_hip;
 // image.astype(np.int64) (pflib.py:241, 443) gives for a float16 image.  Negative / NaN -> 0, +inf -> 65535.
 __device__ __forceinline__ unsigned fsq_pixel(const uint16_t* p, size_t i, int fmt)
 {
+    if (fmt == 2) return ((const uint32_t*)p)[i];    // FSQ_PIXELS_U32 (the pointer is the image's base: i counts pixels)
     const unsigned raw = p[i];
     if (fmt == 0) return raw;
     const unsigned e = (raw >> 10) & 31u, m = raw & 1023u;

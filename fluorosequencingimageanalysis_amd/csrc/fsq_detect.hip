@@ -84,7 +84,8 @@ __device__ __forceinline__ int median25(const int* s)
 }
 
 // generic rank selection for other window sizes (rank = nwin/2 like scipy's median_filter)
-__device__ int median_generic(const unsigned short* raw, int pitch, int r0, int c0, int med)
+template <typename PX>
+__device__ int median_generic(const PX* raw, int pitch, int r0, int c0, int med)
 {
     int nwin = med * med, rank = nwin / 2;
     for (int a = 0; a < nwin; a++) {
@@ -102,7 +103,10 @@ __device__ int median_generic(const unsigned short* raw, int pitch, int r0, int 
 
 // ---------------------------------------------------------------------------------------------
 // K1. grid = (ceil(W/TW), ceil(H/TH), n_fields), block = 256.
-template <bool FAST5>
+// PX = the word the raw tile is staged in: unsigned short for the 16-bit formats, unsigned for FSQ_PIXELS_U32 (values < 2^31:
+// pixel differences fit an int, products with a 32-bit matrix entry and their sum over the window fit an int64 by the
+// domain check of fsq_detect).
+template <bool FAST5, typename PX = unsigned short>
 __global__ void __launch_bounds__(256) k1_response(const uint16_t* __restrict__ img, int pix_fmt, int H, int W, DetectConst dc,
                                                    long long* __restrict__ cm, unsigned long long* __restrict__ field_sum)
 {
@@ -112,17 +116,17 @@ __global__ void __launch_bounds__(256) k1_response(const uint16_t* __restrict__ 
     const int kc = (ksz - 1) / 2;
     const int MH = TH + 2 * kc, MW = TW + 2 * kc;    // mf region
     const int RH = MH + mo + me, RW = MW + mo + me;  // raw region
-    unsigned short* raw = (unsigned short*)smem;                      // [RH][RW]
-    int* mf = (int*)(smem + (((size_t)RH * RW * 2 + 15) & ~(size_t)15));   // [MH][MW]
+    PX* raw = (PX*)smem;                                              // [RH][RW]
+    int* mf = (int*)(smem + (((size_t)RH * RW * sizeof(PX) + 15) & ~(size_t)15));   // [MH][MW]
     const int f = blockIdx.z;
     const int h0 = blockIdx.y * TH, w0 = blockIdx.x * TW;
-    const uint16_t* im = img + (size_t)f * H * W;
+    const uint16_t* im = img + (size_t)f * H * W * (sizeof(PX) / 2);
     const int tid = threadIdx.x;
 
     for (int i = tid; i < RH * RW; i += 256) {       // raw tile with 'reflect' indexing
         int rr = i / RW, cc = i - rr * RW;
         int gh = reflect_idx(h0 - kc - mo + rr, H), gw = reflect_idx(w0 - kc - mo + cc, W);
-        raw[i] = (unsigned short)fsq_pixel(im, (size_t)gh * W + gw, pix_fmt);
+        raw[i] = (PX)fsq_pixel(im, (size_t)gh * W + gw, pix_fmt);
     }
     __syncthreads();
     for (int i = tid; i < MH * MW; i += 256) {       // mf = img - min(median, img); 0 outside the image
@@ -529,7 +533,9 @@ extern "C" int fsq_detect(const uint16_t* d_img, int n_fields, int H, int W, con
     if (!prm) return FSQ_EINVAL;
     const int med = prm->median_filter_size, ksz = prm->ksz;
     if (ksz < 1 || (ksz % 2) == 0) return FSQ_EINVAL;                 // pflib.py:236-239 -> ValueError
-    if (prm->pixel_format != FSQ_PIXELS_U16 && prm->pixel_format != FSQ_PIXELS_F16) return FSQ_EINVAL;
+    if (prm->pixel_format != FSQ_PIXELS_U16 && prm->pixel_format != FSQ_PIXELS_F16 && prm->pixel_format != FSQ_PIXELS_U32) return FSQ_EINVAL;
+    const bool wide = prm->pixel_format == FSQ_PIXELS_U32;
+    if (wide && (prm->pixel_bits < 0 || prm->pixel_bits > 31)) return FSQ_EINVAL;
     if (ksz > MAXK || med < 1 || med > MAXK) return FSQ_ENOTIMPL;
     if (n_fields < 1 || H < 1 || W < 1 || cap < 0 || !d_img || !d_counts || !d_offsets || !d_workspace) return FSQ_EINVAL;
     if (cap > 0 && !d_cand) return FSQ_EINVAL;
@@ -545,9 +551,15 @@ extern "C" int fsq_detect(const uint16_t* d_img, int n_fields, int H, int W, con
     // exactness domain: the integer sum of the response must not wrap (its float64 exactness, < 2^53, is checked
     // on the actual data by k2_scan_all)
     {
-        long double kmax = 0;
-        for (int i = 0; i < ksz * ksz; i++) if (dc.K[i] > 0) kmax += dc.K[i];
-        if (kmax * 65535.0L * (long double)H * W >= 18446744073709551615.0L) return FSQ_ENOTIMPL;
+        long double kmax = 0, kabs = 0;
+        for (int i = 0; i < ksz * ksz; i++) {
+            if (dc.K[i] > 0) kmax += dc.K[i];
+            kabs += dc.K[i] > 0 ? (long double)dc.K[i] : -(long double)dc.K[i];
+        }
+        const int bits = wide ? (prm->pixel_bits ? prm->pixel_bits : 31) : 16;
+        const long double pmax = (long double)((1ull << bits) - 1);
+        if (kabs * pmax >= 9223372036854775807.0L) return FSQ_ENOTIMPL;                 // one pixel's window sum (int64)
+        if (kmax * pmax * (long double)H * W >= 18446744073709551615.0L) return FSQ_ENOTIMPL;
     }
     hipStream_t s = (hipStream_t)stream;
     unsigned char* ws = (unsigned char*)d_workspace;
@@ -563,9 +575,12 @@ extern "C" int fsq_detect(const uint16_t* d_img, int n_fields, int H, int W, con
     {
         const int mo = med / 2, me = med - 1 - mo, kc = (ksz - 1) / 2;
         const int MH = TH + 2 * kc, MW = TW + 2 * kc, RH = MH + mo + me, RW = MW + mo + me;
-        size_t shm = (((size_t)RH * RW * 2 + 15) & ~(size_t)15) + (size_t)MH * MW * 4;
+        size_t shm = (((size_t)RH * RW * (wide ? 4 : 2) + 15) & ~(size_t)15) + (size_t)MH * MW * 4;
         dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, n_fields);
-        if (med == 5 && ksz <= 9 && !getenv("FSQ_DETECT_R03")) {
+        if (wide) {           // 32-bit pixels: the generic tile kernel with a 32-bit raw tile
+            if (med == 5) hipLaunchKernelGGL((k1_response<true, unsigned>), grid, dim3(256), shm, s, d_img, prm->pixel_format, H, W, dc, cm, field_sum);
+            else hipLaunchKernelGGL((k1_response<false, unsigned>), grid, dim3(256), shm, s, d_img, prm->pixel_format, H, W, dc, cm, field_sum);
+        } else if (med == 5 && ksz <= 9 && !getenv("FSQ_DETECT_R03")) {
             // a correlation matrix whose entries depend on the ring only (the default one) needs three multiplications per pixel
             bool ring = (ksz == 5);
             for (int a = 0; a < 5 && ring; a++)

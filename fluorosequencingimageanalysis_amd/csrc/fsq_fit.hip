@@ -172,6 +172,10 @@ extern "C" int fsq_fit_candidates(const uint16_t* d_img, int n_fields, int H, in
 #else
     if ((mode & FSQ_PIXELS_F16_FLAG) && (mode & (FSQ_ENGINE_LANE | FSQ_ENGINE_QUAD))) return FSQ_ENOTIMPL;   // A/B engines: uint16 only
 #endif
+    if (mode & FSQ_PIXELS_U32_FLAG) {       // uint32 pixels (round 4): the rounds engine's 32-bit instantiations, fp64 modes only
+        if ((mode & (FSQ_PIXELS_F16_FLAG | FSQ_ENGINE_LANE | FSQ_ENGINE_QUAD)) || m == FSQ_MODE_TEXTBOOK_F32) return FSQ_ENOTIMPL;
+        return fsq_launch_fit_rounds(d_img, H, W, d_cand, n, m | FSQ_PIXELS_U32_FLAG, true, d_rows, d_workspace, workspace_bytes, (hipStream_t)stream);
+    }
     if (mode & FSQ_PIXELS_F16_FLAG)
         return fsq_launch_fit_rounds(d_img, H, W, d_cand, n, m | FSQ_PIXELS_F16_FLAG, true, d_rows, d_workspace, workspace_bytes, (hipStream_t)stream);
 #ifdef FSQ_BUILD_AB

@@ -91,7 +91,9 @@ struct FitStat {              // by candidate: ROI statistics (kinit)
 // FsqFitQueue) owns a contiguous range of slots while it is in flight, and its queue records carry (slot, ticket).
 // The round kernels only ever see slots - fits of several batches share the queues and the launches.
 struct Ctx {
-    uint16_t* roi;            // [pool][32]: the 25 pixels of every ROI, gathered once by kinit (64 bytes per fit)
+    uint16_t* roi;            // [pool][32]: the 25 pixels of every ROI, gathered once by kinit (64 bytes per fit; with pix32 the
+                              // same slots hold uint32 words: 128 bytes per fit)
+    int pix32;                // FSQ_PIXELS_U32 images: the fit kernels' P32 instantiations
     FitOut* out;              // [pool]
     FitStat* stat;            // [pool]
     long long cap;            // queue capacity (positions)
@@ -206,11 +208,11 @@ FSQ_DEV void roi_pixels(const BatchArgs& c, long long idx, double* d)
 {
     if (c.from_image) {
         const int f = c.cand[3 * idx], h = c.cand[3 * idx + 1], w = c.cand[3 * idx + 2];
-        const uint16_t* base = c.src + ((size_t)f * c.H + (h - 2)) * c.W + (w - 2);
+        const size_t base = ((size_t)f * c.H + (h - 2)) * c.W + (w - 2);      // (in pixels: fsq_pixel knows the word size)
 #pragma unroll
         for (int a = 0; a < 5; a++)
 #pragma unroll
-            for (int b = 0; b < 5; b++) d[a * 5 + b] = (double)fsq_pixel(base, (size_t)a * c.W + b, c.pix_fmt);
+            for (int b = 0; b < 5; b++) d[a * 5 + b] = (double)fsq_pixel(c.src, base + (size_t)a * c.W + b, c.pix_fmt);
     } else {
 #pragma unroll
         for (int k = 0; k < FSQ_NPIX; k++) d[k] = (double)c.src[idx * FSQ_NPIX + k];
@@ -220,6 +222,12 @@ FSQ_DEV void roi_pixels(const BatchArgs& c, long long idx, double* d)
 // the 25 pixels of fit idx from the compact copy (one 64-byte line instead of five image rows)
 FSQ_DEV void roi_compact(const Ctx& c, long long idx, double* d)
 {
+    if (c.pix32) {
+        const uint32_t* s32 = (const uint32_t*)c.roi + (size_t)idx * 32;
+#pragma unroll
+        for (int k = 0; k < FSQ_NPIX; k++) d[k] = (double)s32[k];
+        return;
+    }
     const uint16_t* src = c.roi + (size_t)idx * 32;
     const uint4 a = nt_ld4(src), b = nt_ld4(src + 8), e = nt_ld4(src + 16), f = nt_ld4(src + 24);
     const unsigned w[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, e.x, e.y, e.z, e.w, f.x, f.y, f.z, f.w};
@@ -237,7 +245,11 @@ __global__ void __launch_bounds__(256) kinit(Ctx c, BatchArgs b, double* __restr
     const long long slot = fsq_guard(c, b.base + i, c.pool, G_KINIT_SLOT);
     double v[FSQ_NPIX];
     roi_pixels(b, i, v);
-    if (ok) {
+    if (ok && c.pix32) {
+        uint32_t* dst = (uint32_t*)c.roi + (size_t)slot * 32;
+#pragma unroll
+        for (int k = 0; k < 32; k++) dst[k] = (k < FSQ_NPIX) ? (unsigned)v[k] : 0u;
+    } else if (ok) {
         unsigned w[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) {
@@ -372,7 +384,7 @@ FSQ_DEV double kag_dot25(const double* lds, int grp, int off)
 #else
 #define KA_HZ(code, cond) do { if (cond) hz = true; } while (0)
 #endif
-template <bool FAST, int L>
+template <bool FAST, int L, bool P32 = false>
 __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const double* __restrict__ QA, const int* __restrict__ cntA_p,
                                                                     double* __restrict__ QB, int* __restrict__ cnt_cur,
                                                                     double* __restrict__ SQ, int* __restrict__ slow_cnt,
@@ -433,11 +445,16 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
         int status = 0;
         double gnorm = 0.;
         uint4 roi = make_uint4(0u, 0u, 0u, 0u);     // this lane's 32 / L pixels of the compact ROI copy
+        uint4 roi_hi = make_uint4(0u, 0u, 0u, 0u);  // (P32: pixels 4..7 of the lane's eight, one 32-bit word each)
         double ev[MPX];
 #pragma unroll
         for (int m = 0; m < MPX; m++) ev[m] = 0.0;
         if (active) {                       // pixels and E by pool slot: on their way while the parameters are worked on
-            if (L == 4) roi = nt_ld4(c.roi + (size_t)idx * 32 + cl * 8);
+            if (P32) {
+                static_assert(!P32 || L == 4, "32-bit pixels: the four-lane Jacobian round only");
+                const uint32_t* r32 = (const uint32_t*)c.roi + (size_t)idx * 32 + cl * 8;
+                roi = nt_ld4(r32); roi_hi = nt_ld4(r32 + 4);
+            } else if (L == 4) roi = nt_ld4(c.roi + (size_t)idx * 32 + cl * 8);
             else {
                 const unsigned long long w8 = fsq_bits(nt_ld((const double*)(c.roi + (size_t)idx * 32 + cl * 4)));
                 roi.x = (unsigned)w8; roi.y = (unsigned)(w8 >> 32);
@@ -483,10 +500,11 @@ __global__ void __launch_bounds__(64, (L == 8 ? 4 : 2)) kA_jacobian(Ctx c, const
                      !(__builtin_fabs(xx[3]) <= 0x1p100);
             {   // the pixels and E have arrived by now: lane cl converts its 32 / L pixels of the ROI copy
                 const unsigned w[4] = {roi.x, roi.y, roi.z, roi.w};
+                const unsigned w32[8] = {roi.x, roi.y, roi.z, roi.w, roi_hi.x, roi_hi.y, roi_hi.z, roi_hi.w};
 #pragma unroll
                 for (int t = 0; t < 32 / L; t++) {
                     const int k = cl * (32 / L) + t;
-                    if (k < FSQ_NPIX) QL(Q_DATA, k) = (double)((w[t >> 1] >> (16 * (t & 1))) & 0xffffu);
+                    if (k < FSQ_NPIX) QL(Q_DATA, k) = P32 ? (double)w32[t & 7] : (double)((w[t >> 1] >> (16 * (t & 1))) & 0xffffu);
                 }
                 if (!fresh) {
 #pragma unroll
@@ -1073,7 +1091,7 @@ FSQ_DEV bool kb_trial_gauss(const double* p, double* myscr)
 FSQ_DEV double kb_late_load(const NtRef r) { asm volatile("" ::: "memory"); return (double)r; }
 
 struct KbLimits { int lim[4]; };        // lmpar iteration limits of the four kinds of tiles: B lo, B hi, C 1, C 3
-template <bool ALIASED>
+template <bool ALIASED, bool P32 = false>
 __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double* __restrict__ QB, const double* __restrict__ QC,
                                                   const int* __restrict__ cnt_cur,
                                                   double* __restrict__ QA_next, double* __restrict__ QB_next, double* __restrict__ QC_next,
@@ -1268,12 +1286,21 @@ __global__ void __launch_bounds__(64, FSQ_KB_WAVES) kB_step(Ctx c, const double*
                 if (redo) kb_trial_gauss<false>(wa2, myscr);
             }
             const uint16_t* src = c.roi + (size_t)tag_slot(c, tag) * 32;
-            const uint4 a = nt_ld4(src), b = nt_ld4(src + 8), e = nt_ld4(src + 16), f = nt_ld4(src + 24);
-            const unsigned w[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, e.x, e.y, e.z, e.w, f.x, f.y, f.z, f.w};
+            unsigned w[P32 ? 28 : 16];
+            if (P32) {
+                const uint32_t* s32 = (const uint32_t*)c.roi + (size_t)tag_slot(c, tag) * 32;
+#pragma unroll
+                for (int g = 0; g < 7; g++) { const uint4 q4 = nt_ld4(s32 + 4 * g); w[4 * g] = q4.x; w[4 * g + 1] = q4.y; w[4 * g + 2] = q4.z; w[4 * g + 3] = q4.w; }
+            } else {
+                const uint4 a = nt_ld4(src), b = nt_ld4(src + 8), e = nt_ld4(src + 16), f = nt_ld4(src + 24);
+                const unsigned w16[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, e.x, e.y, e.z, e.w, f.x, f.y, f.z, f.w};
+#pragma unroll
+                for (int g = 0; g < 16; g++) w[g] = w16[g];
+            }
             double S[4], d = 0.0;
 #pragma unroll
             for (int i = 0; i < FSQ_NPIX; i++) {
-                const double pix = (double)((w[i >> 1] >> (16 * (i & 1))) & 0xffffu);
+                const double pix = P32 ? (double)w[i] : (double)((w[i >> 1] >> (16 * (i & 1))) & 0xffffu);
                 const double r = pix - (wa2[0] + wa2[1] * myscr[kb_res_slot(i) * 64]);
                 if (i < 4) S[i] = r * r;
                 else if (i < 16) S[i & 3] = S[i & 3] + r * r;
@@ -1666,7 +1693,7 @@ size_t layout_bytes(size_t pool, size_t qcap)
 {
     qcap = cap_round(qcap);
     size_t b = 4096;
-    b += al256(pool * 64) + al256(pool * sizeof(FitOut)) + al256(pool * sizeof(FitStat));
+    b += al256(pool * 128) + al256(pool * sizeof(FitOut)) + al256(pool * sizeof(FitStat));      // (ROI copies: room for 32-bit pixels)
     b += 2 * al256(qcap * A_LEN * 8) + 2 * al256(qcap * B_LEN * 8) + 2 * al256(qcap * C_LEN * 8) + al256(qcap * A_LEN * 8);
     return b;
 }
@@ -1702,7 +1729,8 @@ struct FsqFitQueue {
         ctl = (int*)ws;     // two sets of queue counters (CNT_*), slow total, slow queue, done counters per ticket
         size_t o = 4096;
         c.cap = (long long)qcap;
-        c.roi = (uint16_t*)(ws + o); o += al256(pool * 64);
+        c.roi = (uint16_t*)(ws + o); o += al256(pool * 128);
+        c.pix32 = (mode & FSQ_PIXELS_U32_FLAG) ? 1 : 0;
         c.out = (FitOut*)(ws + o); o += al256(pool * sizeof(FitOut));
         c.stat = (FitStat*)(ws + o); o += al256(pool * sizeof(FitStat));
         QA[0] = (double*)(ws + o); o += al256(qcap * A_LEN * 8);
@@ -1745,7 +1773,11 @@ struct FsqFitQueue {
     int submit(const uint16_t* src, int pix_fmt, int H, int W, const int32_t* cand, long long n, bool from_image, FsqRow* rows, int* ticket)
     {
         if (n < 0 || (n > 0 && (!src || !rows || (from_image && !cand)))) return FSQ_EINVAL;
-        if (pix_fmt != FSQ_PIXELS_U16 && pix_fmt != FSQ_PIXELS_F16) return FSQ_EINVAL;
+        if (pix_fmt != FSQ_PIXELS_U16 && pix_fmt != FSQ_PIXELS_F16 && pix_fmt != FSQ_PIXELS_U32) return FSQ_EINVAL;
+        // 32-bit pixels: an engine created for them (FSQ_PIXELS_U32_FLAG in its mode) takes nothing else, and the other way round
+        // (the compact ROI copies of all batches in flight share one word size); not in the single-precision mode, not with 8 lanes
+        if ((pix_fmt == FSQ_PIXELS_U32) != (c.pix32 != 0)) return FSQ_ENOTIMPL;
+        if (c.pix32 && (f32 || cfg.ka_lanes == 8)) return FSQ_ENOTIMPL;
         int t = -1;
         for (int k = 0; k < FSQ_MAX_TICKETS; k++)
             if (b[k].state == T_FREE) { t = k; break; }
@@ -1796,11 +1828,14 @@ struct FsqFitQueue {
             // reserved a (dead) queue-B slot in this round, and worked off in the same round it would take a second one - the
             // step round's grid is sized for one slot per live fit, and tiles beyond it would never run (a lost fit, a batch
             // that never finishes; found by the round-3 fuzz on noise fields, where hundreds of fits take this path at once).
-            hipLaunchKernelGGL((kA_jacobian<false, 4>), dim3((unsigned)std::min<long long>((alive + 15) / 16, (long long)cus * 8)), dim3(64), 0, s, c, SQ, cSlow, QB[cur], cset[cur], SQ, cSlow, cset[nxt]);
+            if (c.pix32) hipLaunchKernelGGL((kA_jacobian<false, 4, true>), dim3((unsigned)std::min<long long>((alive + 15) / 16, (long long)cus * 8)), dim3(64), 0, s, c, SQ, cSlow, QB[cur], cset[cur], SQ, cSlow, cset[nxt]);
+            else hipLaunchKernelGGL((kA_jacobian<false, 4>), dim3((unsigned)std::min<long long>((alive + 15) / 16, (long long)cus * 8)), dim3(64), 0, s, c, SQ, cSlow, QB[cur], cset[cur], SQ, cSlow, cset[nxt]);
             FSQ_HIP_CHECK(hipMemsetAsync(cSlow, 0, sizeof(int), s));
             slow_pending = 0;
         }
-        if (gA > 0 && cfg.ka_lanes == 8)            // (kA also zeroes the counters of set nxt)
+        if (gA > 0 && c.pix32)
+            hipLaunchKernelGGL((kA_jacobian<true, 4, true>), dim3((unsigned)gA), dim3(64), cfg.ka_lds_pad, s, c, QA[cur], cset[cur] + CNT_A, QB[cur], cset[cur], SQ, cSlow, cset[nxt]);
+        else if (gA > 0 && cfg.ka_lanes == 8)            // (kA also zeroes the counters of set nxt)
             hipLaunchKernelGGL((kA_jacobian<true, 8>), dim3((unsigned)gA), dim3(64), cfg.ka_lds_pad, s, c, QA[cur], cset[cur] + CNT_A, QB[cur], cset[cur], SQ, cSlow, cset[nxt]);
         else if (gA > 0)
             hipLaunchKernelGGL((kA_jacobian<true, 4>), dim3((unsigned)gA), dim3(64), cfg.ka_lds_pad, s, c, QA[cur], cset[cur] + CNT_A, QB[cur], cset[cur], SQ, cSlow, cset[nxt]);
@@ -1814,7 +1849,9 @@ struct FsqFitQueue {
             const bool staged = alive > cfg.two_pass_min && cfg.lm_first < 10;
             KbLimits lims;
             lims.lim[0] = staged ? std::min(cfg.lm_lo, cfg.lm_first) : 10; lims.lim[1] = staged ? cfg.lm_first : 10; lims.lim[2] = staged ? cfg.lm_first : 10; lims.lim[3] = 10;
-            if (ref) hipLaunchKernelGGL((kB_step<true>), dim3((unsigned)gB), dim3(64), cfg.kb_lds_pad, s, c, QB[cur], QC[cur], cset[cur], QA[nxt], QB[nxt], QC[nxt], cset[nxt], lims);
+            if (c.pix32 && ref) hipLaunchKernelGGL((kB_step<true, true>), dim3((unsigned)gB), dim3(64), 0, s, c, QB[cur], QC[cur], cset[cur], QA[nxt], QB[nxt], QC[nxt], cset[nxt], lims);
+            else if (c.pix32) hipLaunchKernelGGL((kB_step<false, true>), dim3((unsigned)gB), dim3(64), 0, s, c, QB[cur], QC[cur], cset[cur], QA[nxt], QB[nxt], QC[nxt], cset[nxt], lims);
+            else if (ref) hipLaunchKernelGGL((kB_step<true>), dim3((unsigned)gB), dim3(64), cfg.kb_lds_pad, s, c, QB[cur], QC[cur], cset[cur], QA[nxt], QB[nxt], QC[nxt], cset[nxt], lims);
             else hipLaunchKernelGGL((kB_step<false>), dim3((unsigned)gB), dim3(64), 0, s, c, QB[cur], QC[cur], cset[cur], QA[nxt], QB[nxt], QC[nxt], cset[nxt], lims);
         }
         boundA = alive;                             // every fit of this round ends in a list of set nxt or is done
@@ -1921,7 +1958,8 @@ int fsq_launch_fit_rounds(const uint16_t* d_src, int H, int W, const int32_t* d_
     FsqFitQueue q;
     int rc = q.init(d_ws, ws_bytes, (size_t)n + 64, (size_t)n + 64, mode, s_user, true);
     if (rc != FSQ_OK) return rc;
-    rc = q.submit(d_src, (mode & FSQ_PIXELS_F16_FLAG) ? FSQ_PIXELS_F16 : FSQ_PIXELS_U16, H, W, d_cand, n, from_image, d_rows, nullptr);
+    rc = q.submit(d_src, (mode & FSQ_PIXELS_U32_FLAG) ? FSQ_PIXELS_U32 : (mode & FSQ_PIXELS_F16_FLAG) ? FSQ_PIXELS_F16 : FSQ_PIXELS_U16, H, W, d_cand, n, from_image,
+                  d_rows, nullptr);
     if (rc != FSQ_OK) return rc;
     while (q.alive > 0) {
         rc = q.advance(q.cfg.max_rounds, 0, nullptr, nullptr);
@@ -1946,7 +1984,7 @@ extern "C" int fsq_fitq_create(FsqFitQueue** out, void* d_workspace, int64_t wor
                                int64_t queue_cap, int mode, void* stream)
 {
     if (!out || pool_slots <= 0 || queue_cap <= 0) return FSQ_EINVAL;
-    if (mode != FSQ_MODE_REF && mode != FSQ_MODE_TEXTBOOK && mode != FSQ_MODE_TEXTBOOK_F32) return FSQ_EINVAL;
+    if (mode != FSQ_MODE_REF && mode != FSQ_MODE_TEXTBOOK && mode != FSQ_MODE_TEXTBOOK_F32) return FSQ_EINVAL;       // (16-bit pixel formats only)
     FsqFitQueue* q = new (std::nothrow) FsqFitQueue();
     if (!q) return FSQ_ENOMEM;
     int rc = q->init(d_workspace, workspace_bytes, (size_t)pool_slots, (size_t)queue_cap, mode, (hipStream_t)stream, false);

@@ -30,6 +30,15 @@ def to_device_u16(images, device=None):
     return torch.from_numpy(a.view(np.int16)).to(device or "cuda", non_blocking=False)
 
 
+def to_device_pixels(words, pixel_format, device=None):
+    """The host words of as_pixel_fields -> device tensor of the same bytes (int16-typed for the 16-bit formats, int32-typed
+    for PIXELS_U32)."""
+    if pixel_format != N.PIXELS_U32:
+        return to_device_u16(words, device)
+    a = np.ascontiguousarray(words, dtype=np.uint32)
+    return _torch().from_numpy(a.view(np.int32)).to(device or "cuda", non_blocking=False)
+
+
 def as_u16_fields(image):
     """One image / a stack as uint16, the way the reference's `image.astype(np.int64)` (pflib.py:241, 443) reads its input:
     integer pixels as they are, floating-point pixels truncated toward zero.  The GPU path works on 16-bit pixels: values
@@ -57,6 +66,16 @@ def as_pixel_fields(image):
         if a.size and not (np.isfinite(a).all() and (a >= 0).all()):
             raise NotImplementedError("float16 pixels must be finite and non-negative")
         return np.ascontiguousarray(a).view(np.uint16), N.PIXELS_F16
+    if a.dtype.kind == "f":
+        if a.size and not np.isfinite(a).all():
+            raise NotImplementedError("non-finite pixel values are not supported by the GPU path")
+        a = a.astype(np.int64)                      # truncation toward zero, as the reference
+    if a.dtype.kind in "iu" and a.dtype.itemsize > 2 and a.size and int(a.max()) > 65535:
+        # beyond 16 bits (round 4): uint32 words, PIXELS_U32 - detection, fits and consolidation as for 16-bit pixels
+        # (stand-alone Engine passes; the streaming fit queue and the 378-byte peak records stay 16-bit)
+        if int(a.min()) < 0 or int(a.max()) >= 2 ** 31:
+            raise NotImplementedError("pixel values outside [0, 2^31) are not supported by the GPU path")
+        return np.ascontiguousarray(a.astype(np.uint32)), N.PIXELS_U32
     return as_u16_fields(a), N.PIXELS_U16
 
 
@@ -74,10 +93,14 @@ def pixel_values(words, pixel_format):
     w = np.asarray(words)
     if pixel_format == N.PIXELS_F16:
         return w.view(np.float16).astype(np.int64)
+    if pixel_format == N.PIXELS_U32:
+        return w.view(np.uint32).astype(np.int64)
     return w.view(np.uint16).astype(np.int64)
 
 
-def detect_params(median_filter_size, correlation_matrix, c_std, pixel_format=N.PIXELS_U16):
+def detect_params(median_filter_size, correlation_matrix, c_std, pixel_format=N.PIXELS_U16, pixel_max=None):
+    """pixel_max (PIXELS_U32): the largest pixel value of the images - its bit length bounds the integer response's
+    exactness domain (FsqDetectParams.pixel_bits); None = 31 bits."""
     K = np.asarray(correlation_matrix)
     if K.ndim != 2 or K.shape[0] != K.shape[1] or K.shape[0] % 2 == 0:
         raise ValueError("correlation_matrix must be square, with an odd number of rows and columns")
@@ -88,6 +111,7 @@ def detect_params(median_filter_size, correlation_matrix, c_std, pixel_format=N.
     p.ksz = int(K.shape[0])
     p.c_std = float(c_std)
     p.pixel_format = int(pixel_format)
+    p.pixel_bits = max(1, int(pixel_max).bit_length()) if (pixel_format == N.PIXELS_U32 and pixel_max is not None) else 0
     flat = K.astype(np.int64).ravel()
     for i, v in enumerate(flat):
         p.K[i] = int(v)
@@ -236,6 +260,8 @@ class Engine:
             raise RuntimeError("this Engine was created without a fit workspace (its fits run in a FitQueue)")
         if pixel_format == N.PIXELS_F16:
             mode |= N.PIXELS_F16_FLAG
+        elif pixel_format == N.PIXELS_U32:
+            mode |= N.PIXELS_U32_FLAG
         rc = self.L.fsq_fit_candidates(d_img.data_ptr(), self.n_fields, self.H, self.W, self.cand.data_ptr(), total,
                                        mode, self.rows.data_ptr(), self.fit_ws.data_ptr(), self.fit_ws.numel(),
                                        self._stream())

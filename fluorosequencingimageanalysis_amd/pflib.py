@@ -71,10 +71,15 @@ def _device_key():
     return torch.cuda.current_device()
 
 
+def _pixel_max(words, fmt):
+    """Largest pixel value of a PIXELS_U32 stack (bounds the detection's integer domain); None for the 16-bit formats."""
+    return int(words.max()) if (fmt == N.PIXELS_U32 and words.size) else None
+
+
 def _psf_candidates(image, median_filter_size=5, correlation_matrix=default_correlation_matrix, c_std=2, **kwargs):
     """Candidate pixels for PSF fitting, as a list [(h, w), ...] in raster order.  Reference pflib.py:217-258."""
     img, fmt = _engine.as_pixel_fields(image)
-    prm = _engine.detect_params(median_filter_size, correlation_matrix, c_std, fmt)  # ValueError as pflib.py:236-239
+    prm = _engine.detect_params(median_filter_size, correlation_matrix, c_std, fmt, _pixel_max(img, fmt))  # ValueError as pflib.py:236-239
     if img.ndim != 2:
         raise ValueError("image must be two-dimensional")
     H, W = img.shape
@@ -82,7 +87,7 @@ def _psf_candidates(image, median_filter_size=5, correlation_matrix=default_corr
         return []
     eng = _cached(("detect", _device_key(), H, W), lambda: _engine.Engine(1, H, W, fit_workspace=False))
     with _CACHE_LOCK:
-        total = eng.detect(_engine.to_device_u16(img), prm)
+        total = eng.detect(_engine.to_device_pixels(img, fmt), prm)
         cand, _, _ = eng.candidates(total)
     return [(int(h), int(w)) for _, h, w in cand]
 
@@ -241,6 +246,35 @@ def _engine_dicts(eng, d_img, pixel_format=N.PIXELS_U16):
     rows, fit, sub = _engine.split_peak_records(rec.cpu().numpy(), pixel_format)
     failed = set(int(f) for f in np.nonzero(nkeep[:eng.n_fields] < 0)[0])
     return _records_to_dicts(rows, fit, sub, offs.cpu().numpy(), failed)
+
+
+def _wide_pass(imgs, prm, r_2_threshold, radius, mode):
+    """find_peptides of a PIXELS_U32 stack (pixel values beyond 16 bits): stand-alone Engine passes (detect -> fit ->
+    consolidate on 32-bit pixels) over slices of the stack; sub_img is cut from the host copy.  The streaming pipeline
+    (fit queue, 378-byte peak records) carries 16-bit pixels only, so this path trades its overlap for generality."""
+    if mode == N.MODE_TEXTBOOK_F32:
+        raise NotImplementedError("solver='textbook_f32' takes 16-bit pixels only")
+    n, H, W = imgs.shape
+    per = max(1, min(n, CHUNK_PIXELS // (H * W)))
+    eng = _cached(("wide", _device_key(), per, H, W), lambda: _engine.Engine(per, H, W))
+    out = []
+    d = np.arange(-2, 3)
+    with _CACHE_LOCK:
+        for f0 in range(0, n, per):
+            part = imgs[f0:f0 + per]
+            if len(part) < per:                     # (the Engine's shape is fixed: pad the last slice with copies of its first field)
+                part = np.concatenate([part, np.repeat(part[:1], per - len(part), axis=0)])
+            d_img = _engine.to_device_pixels(part, N.PIXELS_U32)
+            eng.run(d_img, prm, r_2_threshold, radius, mode, PY2_ROUND)
+            nkeep = eng.nkeep.cpu().numpy()
+            table, offs = eng.kept_table()
+            fit = eng.fit_images(table).cpu().numpy().reshape(-1, 5, 5)
+            rows = table.cpu().numpy().view(N.ROW_DTYPE).reshape(-1)
+            sub = part[rows["field"][:, None, None], (rows["h"][:, None] + d)[:, :, None],
+                       (rows["w"][:, None] + d)[:, None, :]].astype(np.int64)            # pflib.py:443
+            failed = set(int(f) for f in np.nonzero(nkeep[:per] < 0)[0])
+            out.extend(_records_to_dicts(rows, fit, sub, offs.cpu().numpy(), failed)[:min(per, n - f0)])
+    return out
 
 
 #: find_peptides_batch streams a stack through the GPU in chunks of about this many pixels (engine.StreamPipeline)
@@ -593,8 +627,8 @@ def find_peptides_batch(images, median_filter_size=5, correlation_matrix=default
         raise NotImplementedError("fit_type='monte_carlo' draws from an unseeded RNG in the reference "
                                   "(pflib.py:117-177) and is not reproduced")
     # (candidate_pixels: "Not yet implemented" in the reference, pflib.py:374 - accepted and ignored there and here)
-    imgs, fmt = _engine.as_pixel_fields(images)            # integer dtypes, floats holding 16-bit values, or float16
-    prm = _engine.detect_params(median_filter_size, correlation_matrix, c_std, fmt)
+    imgs, fmt = _engine.as_pixel_fields(images)            # integer dtypes, floats holding integer values, or float16
+    prm = _engine.detect_params(median_filter_size, correlation_matrix, c_std, fmt, _pixel_max(imgs, fmt))
     if imgs.ndim != 3:
         raise ValueError("images must have shape (n, H, W)")
     n, H, W = imgs.shape
@@ -602,7 +636,13 @@ def find_peptides_batch(images, median_filter_size=5, correlation_matrix=default
         return []
     if H < 5 or W < 5:              # (no candidates: pflib.py:252)
         return [{} for _ in range(n)]
-    if engine is not None:                                  # (a caller-owned Engine: one stand-alone pass)
+    if fmt == N.PIXELS_U32:                                 # pixel values beyond 16 bits
+        if engine is not None:
+            raise NotImplementedError("a caller-owned Engine takes 16-bit pixels")
+        out = _wide_pass(imgs, prm, r_2_threshold, consolidation_radius, mode)
+        if on_chunk is not None:
+            on_chunk(0, out)
+    elif engine is not None:                                # (a caller-owned Engine: one stand-alone pass)
         d_img = _engine.to_device_u16(imgs)
         engine.run(d_img, prm, r_2_threshold, consolidation_radius, mode, PY2_ROUND)
         out = _engine_dicts(engine, d_img, fmt)
@@ -631,6 +671,9 @@ def find_peptides_records(images, median_filter_size=5, correlation_matrix=defau
         raise NotImplementedError("fit_type='monte_carlo' draws from an unseeded RNG in the reference "
                                   "(pflib.py:117-177) and is not reproduced")
     imgs, fmt = _engine.as_pixel_fields(images)
+    if fmt == N.PIXELS_U32:
+        raise NotImplementedError("peak records carry 16-bit sub_img words: pixel values beyond 65535 go through "
+                                  "find_peptides / find_peptides_batch")
     prm = _engine.detect_params(median_filter_size, correlation_matrix, c_std, fmt)
     if imgs.ndim != 3:
         raise ValueError("images must have shape (n, H, W)")
@@ -659,7 +702,7 @@ def count_candidates(images, median_filter_size=5, correlation_matrix=default_co
     """Number of PSF candidates of every field of a stack (one detection pass, no fits): the weights of the
     longest-processing-time partition (pflib.py:1043-1054)."""
     imgs, fmt = _engine.as_pixel_fields(images)
-    prm = _engine.detect_params(median_filter_size, correlation_matrix, c_std, fmt)
+    prm = _engine.detect_params(median_filter_size, correlation_matrix, c_std, fmt, _pixel_max(imgs, fmt))
     if imgs.ndim != 3:
         raise ValueError("images must have shape (n, H, W)")
     n, H, W = imgs.shape
@@ -667,7 +710,7 @@ def count_candidates(images, median_filter_size=5, correlation_matrix=default_co
         return np.zeros(n, np.int64)
     eng = _cached(("count", _device_key(), n, H, W), lambda: _engine.Engine(n, H, W, fit_workspace=False))
     with _CACHE_LOCK:
-        eng.detect(_engine.to_device_u16(imgs), prm)
+        eng.detect(_engine.to_device_pixels(imgs, fmt), prm)
         return eng.counts[:n].cpu().numpy().astype(np.int64)
 
 

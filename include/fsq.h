@@ -46,6 +46,7 @@ extern "C" {
                                  pflib.py:199-212); results are NOT the reference's bit for bit - csrc/fsq_fit_f32.h, DESIGN.md 4.9.
                                  R^2 / rmse / s_n of the row are still computed in fp64 from the fitted parameters */
 #define FSQ_PIXELS_F16_FLAG 0x1000 /* OR into mode (fsq_fit_candidates): d_img holds FSQ_PIXELS_F16 pixels */
+#define FSQ_PIXELS_U32_FLAG 0x2000 /* OR into mode (fsq_fit_candidates): d_img holds FSQ_PIXELS_U32 pixels (uint32[n_fields][H][W]) */
 #define FSQ_ENGINE_LANE 0x100 /* OR into mode: persistent kernel, one GPU lane per fit (A/B timing only) */
 #define FSQ_ENGINE_QUAD 0x200 /* OR into mode: persistent kernel, a quad of lanes per fit (A/B timing only) */
 
@@ -69,6 +70,10 @@ typedef struct FsqRow {
  */
 #define FSQ_PIXELS_U16 0
 #define FSQ_PIXELS_F16 1
+#define FSQ_PIXELS_U32 2   /* round 4: uint32 pixels (values < 2^31) for images beyond 16 bits - the reference computes on int64 whatever it
+                            * is handed.  Taken by fsq_detect, fsq_fit_candidates (| FSQ_PIXELS_U32_FLAG) and fsq_fit_images / fsq_consolidate /
+                            * fsq_kept_rows (format-independent); the fit queue (fsq_fitq_*), fsq_find_peptides' 378-byte records, the
+                            * single-precision mode and the photometry / tracking entry points stay 16-bit (FSQ_ENOTIMPL / uint16 arguments). */
 
 #define FSQ_MAX_KSIZE 15                           /* largest correlation matrix / median window side (round 4: was 9) */
 typedef struct FsqDetectParams {
@@ -76,8 +81,9 @@ typedef struct FsqDetectParams {
     int32_t ksz;                                    /* correlation_matrix side, odd, <= FSQ_MAX_KSIZE */
     double c_std;                                   /* pflib default 2 */
     int64_t K[FSQ_MAX_KSIZE * FSQ_MAX_KSIZE];       /* correlation_matrix, row-major (ksz * ksz entries used) */
-    int32_t pixel_format;                           /* FSQ_PIXELS_U16 / FSQ_PIXELS_F16 of d_img */
-    int32_t reserved;
+    int32_t pixel_format;                           /* FSQ_PIXELS_U16 / FSQ_PIXELS_F16 / FSQ_PIXELS_U32 of d_img */
+    int32_t pixel_bits;                             /* FSQ_PIXELS_U32: significant bits of the largest pixel value (1 .. 31; 0 = 31): the
+                                                     * exactness domain of the integer response is checked against it */
 } FsqDetectParams;
 
 const char* fsq_version(void);

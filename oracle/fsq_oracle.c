@@ -167,8 +167,15 @@ static int cmp_i64(const void *a, const void *b)
 
 /* pflib._psf_candidates (pflib.py:217-258).  cm_out (optional) receives the int64 response
  * image, thr_out the float64 threshold. Returns number of candidates or <0. */
-int fsq_o_candidates(const uint16_t *img, int H, int W, int med_size, const int64_t *K, int ksz,
-                     double c_std, int32_t *hw_out, int cap, int64_t *cm_out, double *thr_out)
+/* pixel i of a frame stored as uint16 (wide = 0) or uint32 (wide = 1): the reference works on image.astype(np.int64)
+ * (pflib.py:241, 443) whatever integer type it is handed */
+static inline int64_t px_at(const void *img, int wide, size_t i)
+{
+    return wide ? (int64_t)((const uint32_t *)img)[i] : (int64_t)((const uint16_t *)img)[i];
+}
+
+static int candidates_any(const void *img, int wide, int H, int W, int med_size, const int64_t *K, int ksz,
+                          double c_std, int32_t *hw_out, int cap, int64_t *cm_out, double *thr_out)
 {
     if (ksz <= 0 || (ksz % 2) == 0) return FSQ_O_EINVAL;          /* pflib.py:236-239 */
     if (med_size <= 0 || H <= 0 || W <= 0) return FSQ_O_EINVAL;
@@ -185,9 +192,9 @@ int fsq_o_candidates(const uint16_t *img, int H, int W, int med_size, const int6
             int t = 0;
             for (int i = 0; i < med_size; i++)
                 for (int j = 0; j < med_size; j++)
-                    win[t++] = img[(size_t)reflect_idx(h + i - mo, H) * W + reflect_idx(w + j - mo, W)];
+                    win[t++] = px_at(img, wide, (size_t)reflect_idx(h + i - mo, H) * W + reflect_idx(w + j - mo, W));
             qsort(win, nwin, sizeof(int64_t), cmp_i64);
-            int64_t v = img[(size_t)h * W + w], m = win[rank];
+            int64_t v = px_at(img, wide, (size_t)h * W + w), m = win[rank];
             mf[(size_t)h * W + w] = v - (m < v ? m : v);                /* pflib.py:243-245 */
         }
     int c = (ksz - 1) / 2;
@@ -224,6 +231,19 @@ int fsq_o_candidates(const uint16_t *img, int H, int W, int med_size, const int6
         }
     free(mf); if (!cm_out) free(cm); free(xd); free(win);
     return n;
+}
+
+int fsq_o_candidates(const uint16_t *img, int H, int W, int med_size, const int64_t *K, int ksz,
+                     double c_std, int32_t *hw_out, int cap, int64_t *cm_out, double *thr_out)
+{
+    return candidates_any(img, 0, H, W, med_size, K, ksz, c_std, hw_out, cap, cm_out, thr_out);
+}
+
+/* the same on uint32 pixels (values < 2^31) */
+int fsq_o_candidates_u32(const uint32_t *img, int H, int W, int med_size, const int64_t *K, int ksz,
+                         double c_std, int32_t *hw_out, int cap, int64_t *cm_out, double *thr_out)
+{
+    return candidates_any(img, 1, H, W, med_size, K, ksz, c_std, hw_out, cap, cm_out, thr_out);
 }
 
 /* ================================================================= model */
@@ -810,15 +830,15 @@ int fsq_o_fit_rois_u16(const uint16_t *rois, int n, int mode, int n_threads, Fsq
 }
 
 /* pflib.find_peptides (pflib.py:284-520) */
-int fsq_o_find_peptides(const uint16_t *img, int H, int W, int med_size, const int64_t *K, int ksz,
-                        double c_std, double r2_thr, int radius, int mode, int n_threads,
-                        FsqORow *rows_out, FsqOFit *fits_out, int32_t *keep_idx, int32_t *key_hw,
-                        int cap, int32_t *n_cand, int32_t *n_keep)
+static int find_peptides_any(const void *img, int wide, int H, int W, int med_size, const int64_t *K, int ksz,
+                             double c_std, double r2_thr, int radius, int mode, int n_threads,
+                             FsqORow *rows_out, FsqOFit *fits_out, int32_t *keep_idx, int32_t *key_hw,
+                             int cap, int32_t *n_cand, int32_t *n_keep)
 {
     if (radius < 2) return FSQ_O_EINVAL;
     int32_t *hw = (int32_t *)malloc((size_t)cap * 2 * sizeof(int32_t));
     if (!hw) return FSQ_O_ENOMEM;
-    int n = fsq_o_candidates(img, H, W, med_size, K, ksz, c_std, hw, cap, NULL, NULL);
+    int n = candidates_any(img, wide, H, W, med_size, K, ksz, c_std, hw, cap, NULL, NULL);
     if (n < 0) { free(hw); return n; }
     *n_cand = n;
     if (n > cap) { free(hw); return FSQ_O_ERANGE; }
@@ -828,7 +848,7 @@ int fsq_o_find_peptides(const uint16_t *img, int H, int W, int med_size, const i
         int64_t roi[NPIX];
         int h = hw[2 * i], w = hw[2 * i + 1];
         for (int a = 0; a < 5; a++)
-            for (int b = 0; b < 5; b++) roi[a * 5 + b] = img[(size_t)(h - 2 + a) * W + (w - 2 + b)];
+            for (int b = 0; b < 5; b++) roi[a * 5 + b] = px_at(img, wide, (size_t)(h - 2 + a) * W + (w - 2 + b));
         FsqOFit f;
         fsq_o_fit_roi(roi, mode, &f);
         if (fits_out) fits_out[i] = f;
@@ -838,6 +858,34 @@ int fsq_o_find_peptides(const uint16_t *img, int H, int W, int med_size, const i
     free(hw);
     if (nk < 0) return nk;
     *n_keep = nk;
+    return 0;
+}
+
+int fsq_o_find_peptides(const uint16_t *img, int H, int W, int med_size, const int64_t *K, int ksz,
+                        double c_std, double r2_thr, int radius, int mode, int n_threads,
+                        FsqORow *rows_out, FsqOFit *fits_out, int32_t *keep_idx, int32_t *key_hw,
+                        int cap, int32_t *n_cand, int32_t *n_keep)
+{
+    return find_peptides_any(img, 0, H, W, med_size, K, ksz, c_std, r2_thr, radius, mode, n_threads, rows_out, fits_out,
+                             keep_idx, key_hw, cap, n_cand, n_keep);
+}
+
+/* the same on uint32 pixels (values < 2^31) */
+int fsq_o_find_peptides_u32(const uint32_t *img, int H, int W, int med_size, const int64_t *K, int ksz,
+                            double c_std, double r2_thr, int radius, int mode, int n_threads,
+                            FsqORow *rows_out, FsqOFit *fits_out, int32_t *keep_idx, int32_t *key_hw,
+                            int cap, int32_t *n_cand, int32_t *n_keep)
+{
+    return find_peptides_any(img, 1, H, W, med_size, K, ksz, c_std, r2_thr, radius, mode, n_threads, rows_out, fits_out,
+                             keep_idx, key_hw, cap, n_cand, n_keep);
+}
+
+/* fits of n 5 x 5 ROIs given as int64 (any pixel width) */
+int fsq_o_fit_rois_i64(const int64_t *rois, int n, int mode, int n_threads, FsqOFit *out)
+{
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(n_threads)
+    for (int i = 0; i < n; i++) fsq_o_fit_roi(rois + (size_t)i * NPIX, mode, &out[i]);
     return 0;
 }
 

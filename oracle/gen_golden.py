@@ -9,7 +9,7 @@ fluorosequencingimageanalysis_amd/synth.py.  The .npz files hold DATA only
 
 Usage (about 4 minutes on 8 cores):
   NPY_DISABLE_CPU_FEATURES="AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL AVX512_SPR" \
-      python oracle/gen_golden.py [--only fields|reg|kat|phot|degen|textbook|io|loader|track|centroid]
+      python oracle/gen_golden.py [--only fields|reg|kat|phot|degen|wide|textbook|io|loader|track|centroid]
 
 Golden sets: G1 per-ROI fits, G2 candidate lists, G3 full
 find_peptides tables, G4 phase_correlate tuples, G5 known-answer tests.
@@ -131,6 +131,19 @@ def degenerate_images():
     hot[20, 22] = 30000
     out["d6_hotpixel_32"] = hot
     out["d7_zero_24"] = np.zeros((24, 24), np.uint16)
+    return out
+
+
+def wide_images():
+    """Frames whose pixel values do not fit 16 bits (uint32 arrays; the reference computes on image.astype(np.int64),
+    pflib.py:241, 443, whatever integer type it is handed) -> tests/golden/wide_*.npz, the vectors of FSQ_PIXELS_U32."""
+    out = {}
+    out["w0_22bit_128"] = synth.make_field(41, (128, 128), 14).astype(np.uint32) * 37 + 70000
+    out["w1_28bit_96"] = synth.make_field(42, (96, 96), 10).astype(np.uint32) * 4099
+    mixed = synth.make_field(43, (96, 96), 10).astype(np.uint32)          # 16-bit background, peaks far beyond it
+    out["w2_mixed_96"] = np.where(mixed > 1500, mixed * 53, mixed).astype(np.uint32)
+    hard = synth.make_hard_field(44, (112, 112), 40).astype(np.uint32)
+    out["w3_hard_20bit_112"] = hard * 16 + (np.arange(112 * 112, dtype=np.uint32).reshape(112, 112) * 2654435761 >> 28)
     return out
 
 
@@ -566,6 +579,9 @@ def main():
         with mp.Pool(a.procs) as pool:
             gen_fields(pool, with_stability=(), fields={k: {"image": v} for k, v in degenerate_images().items()},
                        prefix="degen_")
+    if a.only in ("", "wide"):
+        with mp.Pool(a.procs) as pool:
+            gen_fields(pool, with_stability=(), fields={k: {"image": v} for k, v in wide_images().items()}, prefix="wide_")
     if a.only in ("", "textbook"):
         # the reference with MINPACK's qrsolv (x = numpy.diagonal(r).copy(), refload.load_reference(textbook_qrsolv=True)):
         # pins the oracle's / the GPU's FSQ_MODE_TEXTBOOK.  A fresh interpreter so that every worker loads that variant.

@@ -63,15 +63,25 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+def _pixels(img):
+    """(contiguous array, wide): uint16 frames as they are, anything wider as uint32 (values < 2^31)."""
+    img = np.asarray(img)
+    if img.dtype.itemsize > 2 and img.dtype.kind in "iu":
+        if img.size and (int(img.min()) < 0 or int(img.max()) >= 2 ** 31):
+            raise ValueError("pixel values outside [0, 2^31)")
+        return np.ascontiguousarray(img, dtype=np.uint32), True
+    return np.ascontiguousarray(img, dtype=np.uint16), False
+
+
 def candidates(img, med_size=5, K=DEFAULT_K, c_std=2.0, libm=False, return_cm=False):
-    img = np.ascontiguousarray(img, dtype=np.uint16)
+    img, wide = _pixels(img)
     K = np.ascontiguousarray(K, dtype=np.int64)
     H, W = img.shape
     cap = H * W
     hw = np.empty((cap, 2), np.int32)
     cm = np.empty((H, W), np.int64)
     thr = ctypes.c_double()
-    n = lib(libm).fsq_o_candidates(_p(img), H, W, int(med_size), _p(K), K.shape[0], ctypes.c_double(c_std),
+    n = (lib(libm).fsq_o_candidates_u32 if wide else lib(libm).fsq_o_candidates)(_p(img), H, W, int(med_size), _p(K), K.shape[0], ctypes.c_double(c_std),
                                    _p(hw), cap, _p(cm), ctypes.byref(thr))
     if n < 0:
         raise ValueError("oracle candidates error %d" % n)
@@ -81,8 +91,13 @@ def candidates(img, med_size=5, K=DEFAULT_K, c_std=2.0, libm=False, return_cm=Fa
 
 
 def fit_rois(rois, mode=0, n_threads=1, libm=False):
+    rois = np.asarray(rois)
+    out = np.zeros(rois.size // 25, FIT_DTYPE)
+    if rois.dtype.itemsize > 2 and rois.dtype.kind in "iu":
+        rois = np.ascontiguousarray(rois, dtype=np.int64).reshape(-1, 25)
+        lib(libm).fsq_o_fit_rois_i64(_p(rois), len(rois), int(mode), int(n_threads), _p(out))
+        return out
     rois = np.ascontiguousarray(rois, dtype=np.uint16).reshape(-1, 25)
-    out = np.zeros(len(rois), FIT_DTYPE)
     lib(libm).fsq_o_fit_rois_u16(_p(rois), len(rois), int(mode), int(n_threads), _p(out))
     return out
 
@@ -102,7 +117,7 @@ def illumina_s_n(roi, libm=False):
 def find_peptides(img, med_size=5, K=DEFAULT_K, c_std=2.0, r2_thr=0.7, radius=4, mode=0, n_threads=1,
                   libm=False):
     """Returns (rows[all candidates], fits, keep_idx, key_hw)."""
-    img = np.ascontiguousarray(img, dtype=np.uint16)
+    img, wide = _pixels(img)
     K = np.ascontiguousarray(K, dtype=np.int64)
     H, W = img.shape
     cap = H * W
@@ -111,7 +126,7 @@ def find_peptides(img, med_size=5, K=DEFAULT_K, c_std=2.0, r2_thr=0.7, radius=4,
     keep = np.zeros(cap, np.int32)
     key = np.zeros((cap, 2), np.int32)
     nc, nk = ctypes.c_int32(), ctypes.c_int32()
-    rc = lib(libm).fsq_o_find_peptides(_p(img), H, W, int(med_size), _p(K), K.shape[0],
+    rc = (lib(libm).fsq_o_find_peptides_u32 if wide else lib(libm).fsq_o_find_peptides)(_p(img), H, W, int(med_size), _p(K), K.shape[0],
                                        ctypes.c_double(c_std), ctypes.c_double(r2_thr), int(radius),
                                        int(mode), int(n_threads), _p(rows), _p(fits), _p(keep), _p(key),
                                        cap, ctypes.byref(nc), ctypes.byref(nk))

@@ -1,0 +1,199 @@
+"""GPU parity tests (-m gpu) of FSQ_PIXELS_U32: frames whose pixel values do not fit 16 bits (the reference computes on
+image.astype(np.int64), pflib.py:241, 443, whatever integer type it is handed).  Detection, every LM solve and the
+consolidated table, through the C ABI (fsq_detect / fsq_fit_candidates | FSQ_PIXELS_U32_FLAG / fsq_consolidate), against the
+reference's recorded outputs (tests/golden/wide_*.npz, oracle/gen_golden.py --only wide) and against the oracle on seeded
+stacks - bit for bit."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from _util import WIDE_NAMES, bits_equal, load_field
+
+pytestmark = pytest.mark.gpu
+
+P7 = ("H", "A", "p2", "p3", "sigma_h", "sigma_w", "theta")
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from fluorosequencingimageanalysis_amd import _native, engine, pflib, synth
+    import oracle as O
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    O.build()
+    return torch, _native, engine, pflib, synth, O
+
+
+def _fit_all_candidates(env, img):
+    """detect + fit of one uint32 frame through a stand-alone Engine -> (candidates int32[n, 2], FsqRow[n])."""
+    torch, N, E, pflib, synth, O = env
+    H, W = img.shape
+    eng = E.Engine(1, H, W)
+    prm = E.detect_params(5, pflib.default_correlation_matrix, 2, N.PIXELS_U32, int(img.max()))
+    d_img = E.to_device_pixels(img[None], N.PIXELS_U32)
+    total = eng.detect(d_img, prm)
+    eng.fit(d_img, total, N.MODE_REF, N.PIXELS_U32)
+    torch.cuda.synchronize()
+    cand = eng.cand[:total].cpu().numpy()[:, 1:3]
+    return cand, eng.rows[:total].cpu().numpy().view(N.ROW_DTYPE).reshape(-1)
+
+
+def _table_of(d):
+    vals = list(d.values())
+    keys = np.array(list(d.keys()), dtype=np.int32).reshape(-1, 2)
+    t7 = np.array([[float(x) for x in v[:7]] for v in vals]).reshape(-1, 7)
+    sub = np.array([v[7] for v in vals], dtype=np.int64).reshape(-1, 5, 5)
+    fit = np.array([v[8] for v in vals], dtype=np.float64).reshape(-1, 5, 5)
+    m = np.array([[float(v[9]), float(v[10]), float(v[11])] for v in vals]).reshape(-1, 3)
+    return keys, t7, sub, fit, m
+
+
+@pytest.mark.parametrize("name", WIDE_NAMES)
+def test_frames_beyond_16_bits_equal_reference(env, name):
+    torch, N, E, pflib, synth, O = env
+    g, img = load_field(name, prefix="wide_")
+    assert img.dtype == np.uint32 and int(img.max()) > 65535
+    assert pflib._psf_candidates(img) == [tuple(int(v) for v in hw) for hw in g["candidates"]]
+    cand, rows = _fit_all_candidates(env, img)
+    assert np.array_equal(cand, g["candidates"])
+    p = np.stack([rows[k] for k in P7], axis=1)
+    assert bits_equal(p, g["params"]).all()
+    for k in ("status", "niter", "nfev"):
+        assert np.array_equal(rows[k], g[k]), k
+    keys, t7, sub, fit, m = _table_of(pflib.find_peptides(img))
+    assert np.array_equal(keys, g["table_keys"].reshape(-1, 2))
+    assert bits_equal(t7, g["table7"].reshape(-1, 7)).all()
+    assert np.array_equal(sub, g["table_sub"])
+    assert bits_equal(fit, g["table_fit"]).all()
+    assert bits_equal(m, g["table_metrics"].reshape(-1, 3)).all()
+
+
+def _wide_stack(synth, seeds, shape, n_spots):
+    """Seeded uint32 frames: synthetic fields scaled by per-frame factors into 17 .. 30 bits, some with an offset."""
+    out = []
+    for s in seeds:
+        rng = np.random.default_rng([s, 0x51DE])
+        f = synth.make_hard_field(s, shape, n_spots) if s % 3 == 0 else synth.make_field(s, shape, n_spots)
+        k = int(rng.integers(3, 16000))
+        out.append(f.astype(np.uint32) * k + int(rng.integers(0, 2) * rng.integers(0, 1 << 20)))
+    return np.stack(out)
+
+
+def test_stack_equals_oracle(env):
+    """find_peptides_batch of 24 seeded wide frames (more than one Engine slice, the last one padded) == the oracle's
+    find_peptides, field by field: keys in order, parameters, sub_img, metrics."""
+    torch, N, E, pflib, synth, O = env
+    imgs = _wide_stack(synth, range(200, 224), (160, 144), 40)
+    assert int(imgs.max()) > 1 << 24
+    old = pflib.CHUNK_PIXELS
+    pflib.CHUNK_PIXELS = 10 * 160 * 144                 # 10 fields per slice: 10 + 10 + 4
+    try:
+        got = pflib.find_peptides_batch(imgs, errors='return')
+    finally:
+        pflib.CHUNK_PIXELS = old
+    n_peaks = 0
+    for f, d in enumerate(got):
+        try:
+            rows, fits, keep, key = O.find_peptides(imgs[f], n_threads=16)
+        except AssertionError:
+            assert isinstance(d, AssertionError), f
+            continue
+        keys, t7, sub, fit, m = _table_of(d)
+        assert np.array_equal(keys, key), f
+        r = rows[keep]
+        assert bits_equal(t7, np.stack([r[k] for k in ("h0", "w0", "H", "A", "sigma_h", "sigma_w", "theta")], axis=1)).all(), f
+        assert bits_equal(m, np.stack([r["rmse"], r["r2"], r["s_n"]], axis=1)).all(), f
+        exp_sub = np.stack([imgs[f][h - 2:h + 3, w - 2:w + 3] for h, w in zip(r["h"], r["w"])]).astype(np.int64) if len(r) else sub
+        assert np.array_equal(sub, exp_sub), f
+        n_peaks += len(keys)
+    assert n_peaks > 300
+
+
+def test_every_fit_equals_oracle(env):
+    """All candidates' solves of wide frames (kept or not) vs the oracle: parameters, status, iteration and evaluation
+    counts, and the metrics of the row."""
+    torch, N, E, pflib, synth, O = env
+    n = 0
+    for s in (301, 303, 304):
+        img = _wide_stack(synth, [s], (256, 256), 150)[0]
+        cand, rows = _fit_all_candidates(env, img)
+        assert np.array_equal(cand, O.candidates(img))
+        rois = np.stack([img[h - 2:h + 3, w - 2:w + 3] for h, w in cand]).reshape(-1, 25)
+        ref = O.fit_rois(rois, n_threads=16)
+        assert bits_equal(np.stack([rows[k] for k in P7], axis=1), ref["p"]).all()
+        for k in ("status", "niter", "nfev"):
+            assert np.array_equal(rows[k], ref[k]), k
+        orows = O.find_peptides(img, n_threads=16)[0]
+        for k in ("rmse", "r2", "s_n", "h0", "w0"):
+            assert bits_equal(rows[k], orows[k]).all(), k
+        n += len(cand)
+    assert n > 1000
+
+
+def test_small_values_in_wide_dtypes_take_the_16_bit_path(env):
+    """A uint32 / int64 / float64 array whose values fit 16 bits is the same image as its uint16 copy."""
+    torch, N, E, pflib, synth, O = env
+    img = synth.make_field(9, (128, 128), 20)
+    ref = pflib.find_peptides(img)
+    for dt in (np.uint32, np.int64, np.float64):
+        words, fmt = E.as_pixel_fields(img.astype(dt))
+        assert fmt == N.PIXELS_U16 and words.dtype == np.uint16
+    words, fmt = E.as_pixel_fields(img.astype(np.int64) * 1000)
+    assert fmt == N.PIXELS_U32 and words.dtype == np.uint32
+    words, fmt = E.as_pixel_fields(img.astype(np.float64) * 1000.5)
+    assert fmt == N.PIXELS_U32 and np.array_equal(words, (img.astype(np.float64) * 1000.5).astype(np.int64))
+    got = pflib.find_peptides(img.astype(np.uint32))
+    assert list(got.keys()) == list(ref.keys())
+    with pytest.raises(NotImplementedError):
+        E.as_pixel_fields(np.full((8, 8), 2 ** 31, np.int64))
+    with pytest.raises(NotImplementedError):
+        E.as_pixel_fields(np.array([[70000, -1]], np.int64))
+
+
+def test_wide_pixels_same_values_same_results(env):
+    """A 16-bit frame handed over as FSQ_PIXELS_U32 words gives the rows of the 16-bit path, byte for byte (the 32-bit
+    instantiations of the kernels against the 16-bit ones)."""
+    torch, N, E, pflib, synth, O = env
+    img = synth.make_hard_field(77, (192, 192), 90)
+    cand32, rows32 = _fit_all_candidates(env, img.astype(np.uint32))
+    H, W = img.shape
+    eng = E.Engine(1, H, W)
+    prm = E.detect_params(5, pflib.default_correlation_matrix, 2)
+    d_img = E.to_device_u16(img[None])
+    total = eng.detect(d_img, prm)
+    eng.fit(d_img, total)
+    torch.cuda.synchronize()
+    assert total == len(cand32) and np.array_equal(eng.cand[:total].cpu().numpy()[:, 1:3], cand32)
+    assert eng.rows[:total].cpu().numpy().tobytes() == rows32.tobytes()
+
+
+def test_entry_points_that_stay_16_bit_say_so(env):
+    torch, N, E, pflib, synth, O = env
+    L = N.lib()
+    img = _wide_stack(synth, [5], (64, 64), 6)
+    d_img = E.to_device_pixels(img, N.PIXELS_U32)
+    eng = E.Engine(1, 64, 64)
+    prm = E.detect_params(5, pflib.default_correlation_matrix, 2, N.PIXELS_U32, int(img.max()))
+    total = eng.detect(d_img, prm)
+    assert total > 0
+    args = (d_img.data_ptr(), 1, 64, 64, eng.cand.data_ptr(), total)
+    tail = (eng.rows.data_ptr(), eng.fit_ws.data_ptr(), eng.fit_ws.numel(), None)
+    assert L.fsq_fit_candidates(*args, N.MODE_TEXTBOOK_F32 | N.PIXELS_U32_FLAG, *tail) == N.FSQ_ENOTIMPL
+    assert L.fsq_fit_candidates(*args, N.MODE_REF | N.PIXELS_U32_FLAG | N.PIXELS_F16_FLAG, *tail) == N.FSQ_ENOTIMPL
+    assert L.fsq_fit_candidates(*args, N.MODE_REF | N.PIXELS_U32_FLAG | N.ENGINE_QUAD, *tail) == N.FSQ_ENOTIMPL
+    q = E.FitQueue(1 << 12, 1 << 12)
+    with pytest.raises(NotImplementedError):
+        q.submit(d_img, 1, 64, 64, eng.cand, total, eng.rows, N.PIXELS_U32)
+    prm.pixel_bits = 40
+    assert L.fsq_detect(d_img.data_ptr(), 1, 64, 64, ctypes.byref(prm), eng.cand.data_ptr(), eng.cap, eng.counts.data_ptr(),
+                        eng.offsets.data_ptr(), eng.thr.data_ptr(), eng.ws.data_ptr(), eng.ws.numel(), None) == N.FSQ_EINVAL
+    with pytest.raises(NotImplementedError):
+        pflib.find_peptides_records(img)
+    with pytest.raises(NotImplementedError):
+        pflib.find_peptides_batch(img, solver='textbook_f32')
+    # a correlation matrix whose window sum could leave int64 with 31-bit pixels is refused, not wrapped
+    big = np.full((15, 15), 2 ** 31 - 1, np.int64)
+    prm = E.detect_params(5, big, 2, N.PIXELS_U32, 2 ** 31 - 1)
+    assert L.fsq_detect(d_img.data_ptr(), 1, 64, 64, ctypes.byref(prm), eng.cand.data_ptr(), eng.cap, eng.counts.data_ptr(),
+                        eng.offsets.data_ptr(), eng.thr.data_ptr(), eng.ws.data_ptr(), eng.ws.numel(), None) == N.FSQ_ENOTIMPL

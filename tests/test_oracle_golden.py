@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import oracle as O
-from _util import DEGEN_NAMES, FIELD_NAMES, GOLD, TEXTBOOK_NAMES, bits_equal, load_field, rois_of
+from _util import DEGEN_NAMES, FIELD_NAMES, GOLD, TEXTBOOK_NAMES, WIDE_NAMES, bits_equal, load_field, rois_of
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -83,6 +83,15 @@ def test_degenerate_frames_match_reference(name):
     mpfit.py:956-964, cannot be reached through pflib: gaussfitter clips the start into the bounds, gaussfitter.py:202-204;
     none of these frames drives a step non-finite, status -16, mpfit.py:1330-1335.)"""
     g, img = load_field(name, prefix="degen_")
+    _check_against_golden(g, img, mode=0)
+
+
+@pytest.mark.parametrize("name", WIDE_NAMES)
+def test_frames_beyond_16_bits_match_reference(name):
+    """uint32 frames with 20- to 28-bit pixel values through the unmodified reference (oracle/gen_golden.py --only wide;
+    pflib works on image.astype(np.int64), pflib.py:241, 443): the vectors behind FSQ_PIXELS_U32."""
+    g, img = load_field(name, prefix="wide_")
+    assert img.dtype == np.uint32 and int(img.max()) > 65535
     _check_against_golden(g, img, mode=0)
 
 
