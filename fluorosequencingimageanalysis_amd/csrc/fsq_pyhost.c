@@ -64,7 +64,11 @@ static PyObject* view5x5(PyArrayObject* block, Py_ssize_t i)
 static PyObject* field_dict(const unsigned char* rec, Py_ssize_t a, Py_ssize_t b, int f16)
 {
     const Py_ssize_t m = b - a;
+#if PY_VERSION_HEX < 0x030d0000
+    PyObject* d = m > 5 ? _PyDict_NewPresized(m) : PyDict_New();     /* (no rehashing while the field's peaks are inserted) */
+#else
     PyObject* d = PyDict_New();
+#endif
     if (!d || m == 0) return d;
     npy_intp dims[3] = {m, 5, 5};
     PyArrayObject* fit = (PyArrayObject*)PyArray_SimpleNew(3, dims, NPY_DOUBLE);
@@ -91,7 +95,12 @@ static PyObject* field_dict(const unsigned char* rec, Py_ssize_t a, Py_ssize_t b
         if (ok) { PyObject* o = PyFloat_FromDouble(rd_f64(r + O_RMSE)); if (!o) ok = 0; else PyTuple_SET_ITEM(t, 9, o); }
         if (ok) { PyObject* o = f64_scalar(rd_f64(r + O_R2)); if (!o) ok = 0; else PyTuple_SET_ITEM(t, 10, o); }
         if (ok) { PyObject* o = f64_scalar(rd_f64(r + O_SN)); if (!o) ok = 0; else PyTuple_SET_ITEM(t, 11, o); }
-        PyObject* key = ok ? Py_BuildValue("(ii)", (int)rd_i32(r + O_KEYH), (int)rd_i32(r + O_KEYW)) : NULL;
+        PyObject* key = ok ? PyTuple_New(2) : NULL;
+        if (key) {
+            PyObject *kh = PyLong_FromLong((long)rd_i32(r + O_KEYH)), *kw = PyLong_FromLong((long)rd_i32(r + O_KEYW));
+            if (!kh || !kw) { Py_XDECREF(kh); Py_XDECREF(kw); Py_CLEAR(key); }
+            else { PyTuple_SET_ITEM(key, 0, kh); PyTuple_SET_ITEM(key, 1, kw); }
+        }
         if (!key || PyDict_SetItem(d, key, t) < 0) { Py_XDECREF(key); Py_DECREF(t); goto fail; }
         Py_DECREF(key);
         Py_DECREF(t);
