@@ -12,6 +12,12 @@ def main():
     import logging
     logging.getLogger().addHandler(logging.NullHandler())      # failures travel back to the parent, which logs them
     from . import pflib
+    try:        # what the jobs import on first use, now: the parent is still busy with its own start-up
+        from PIL import Image, ImageDraw, ImageOps, PngImagePlugin, TiffImagePlugin  # noqa: F401
+        import _compat_pickle  # noqa: F401
+        Image.init()
+    except Exception:       # noqa: BLE001 - the job that needs it reports it
+        pass
     jobs = {"read": pflib._read_job, "save": pflib._save_job, "save_records": pflib._save_records_job}
     inp, out = sys.stdin.buffer, sys.stdout.buffer
     sys.stdout = sys.stderr                     # stray prints must not corrupt the reply stream

@@ -63,6 +63,11 @@ def main(argv=None):
     timestamp_datetime = datetime.datetime.fromtimestamp(timestamp_epoch)
     args = build_parser(timestamp_datetime).parse_args(argv)
     target_directories = [os.path.abspath(d) for d in args.target_directories]
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        # the host worker processes first: they import their modules while this process initialises torch / the GPU
+        # - and so does the GPU side, on a thread: importing torch, the HIP context, loading the library
+        if pflib.prestart_io_workers(len(find_target_images(target_directories)), args.num_processes[0]) is not None:
+            pflib.start_gpu_warmup()
     rank, world, _local = distributed.init_from_env()
     log_path = args.log_path[0] if rank == 0 else args.log_path[0] + '.rank%d' % rank
     logging.basicConfig(filename=log_path, level=logging.DEBUG, force=True)

@@ -5,17 +5,20 @@ is the final variable-length gather of the peak tables to rank 0 (RCCL over xGMI
 The reference's counterpart is pflib.parallel_image_batch (pflib.py:1000-1111): a multiprocessing.Pool
 over image partitions whose "gather" is the file system."""
 import os
+import sys
 
 import numpy as np
 
 
 def init_from_env(backend=None):
     """torch.distributed init from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun). Returns (rank, world, local)."""
-    import torch
-    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world <= 1:
+        return rank, world, local       # (a single process has no group to join, and does not wait for `import torch` here)
+    import torch
+    import torch.distributed as dist
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -29,13 +32,19 @@ def init_from_env(backend=None):
 
 
 def world_size():
-    import torch.distributed as dist
-    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    dist = sys.modules.get("torch.distributed")     # never imported: no process group can exist
+    try:
+        return dist.get_world_size() if (dist is not None and dist.is_available() and dist.is_initialized()) else 1
+    except AttributeError:                          # (another thread is importing it right now: no group yet)
+        return 1
 
 
 def get_rank():
-    import torch.distributed as dist
-    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+    dist = sys.modules.get("torch.distributed")
+    try:
+        return dist.get_rank() if (dist is not None and dist.is_available() and dist.is_initialized()) else 0
+    except AttributeError:
+        return 0
 
 
 def shard_fields(n_fields, rank, world):

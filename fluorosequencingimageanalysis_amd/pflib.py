@@ -982,20 +982,34 @@ class _IoPool:
         self.local = threading.local()
         self.procs = []
         self.lock = threading.Lock()
+        # all workers are started NOW: they import numpy / PIL (0.3 - 0.7 s on a cold machine) while the caller goes on to its
+        # own start-up (the GPU context, the library) instead of each one doing so inside its first job
+        self.idle = collections.deque(self._spawn() for _ in range(self.n))
+
+    def _spawn(self):
+        import subprocess
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ)
+        env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+        w = subprocess.Popen([sys.executable, "-m", "fluorosequencingimageanalysis_amd._io_worker"], stdin=subprocess.PIPE,
+                             stdout=subprocess.PIPE, env=env)
+        with self.lock:
+            self.procs.append(w)
+        return w
 
     def _worker(self):
         w = getattr(self.local, "proc", None)
         if w is None or w.poll() is not None:
-            import subprocess
-            import sys
-            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-            env = dict(os.environ)
-            env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
-            w = subprocess.Popen([sys.executable, "-m", "fluorosequencingimageanalysis_amd._io_worker"], stdin=subprocess.PIPE,
-                                 stdout=subprocess.PIPE, env=env)
-            self.local.proc = w
+            w = None
             with self.lock:
-                self.procs.append(w)
+                while self.idle and w is None:
+                    w = self.idle.popleft()
+                    if w.poll() is not None:
+                        w = None
+            if w is None:
+                w = self._spawn()
+            self.local.proc = w
         return w
 
     def _call(self, name, args):
@@ -1043,6 +1057,48 @@ def _io_pool(n_images, num_processes=None):
             _IO_POOL["pool"] = _IoPool(n)
             _IO_POOL["n"] = n
         return _IO_POOL["pool"]
+
+
+def prestart_io_workers(n_images, num_processes=None):
+    """Start the host worker processes of image_batch ahead of it (the command line does, before it initialises anything else)."""
+    if num_processes is not None and (num_processes < 1 or round(num_processes) != num_processes):
+        return None                 # (parallel_image_batch raises for it)
+    return _io_pool(n_images, num_processes)
+
+
+def _warm_gpu():
+    """The first-use costs of the GPU path - HIP context, loading the library and its code objects, the first allocations -
+    on a tiny frame.  image_batch runs this on a thread while the first window of images is being read; errors are left to the
+    real call to report."""
+    try:
+        img = np.full((1, 48, 48), 100, np.uint16)
+        img[0, 22:27, 22:27] += np.array([[1, 4, 7, 4, 1], [4, 20, 33, 20, 4], [7, 33, 55, 33, 7], [4, 20, 33, 20, 4],
+                                          [1, 4, 7, 4, 1]], np.uint16) * 40
+        find_peptides_records(img)
+    except Exception:       # noqa: BLE001
+        pass
+
+
+_WARM = {"thread": None, "lock": threading.Lock()}
+
+
+def start_gpu_warmup():
+    """Run _warm_gpu on a thread (once at a time).  The command line calls this first thing, so that importing torch (a second
+    or more of interpreter time), creating the HIP context and loading the library overlap the workers' start-up and the reading
+    of the first images; image_batch waits for it before its first GPU pass."""
+    with _WARM["lock"]:
+        t = _WARM["thread"]
+        if t is None or not t.is_alive():
+            t = _WARM["thread"] = threading.Thread(target=_warm_gpu, name="fsq-warm-gpu", daemon=True)
+            t.start()
+    return t
+
+
+def _join_gpu_warmup():
+    with _WARM["lock"]:
+        t, _WARM["thread"] = _WARM["thread"], None
+    if t is not None:
+        t.join()
 
 
 def shutdown_io_workers():
@@ -1109,7 +1165,7 @@ def _read_all(image_paths, pool):
         return
     ahead = collections.deque()
     it = iter(image_paths)
-    limit = 4 * _IO_POOL["n"]
+    limit = 8 * _IO_POOL["n"]
     while True:
         while len(ahead) < limit:
             try:
@@ -1201,6 +1257,8 @@ def image_batch(image_paths, find_peptides_parameters=None, timestamp_epoch=None
         find_peptides_parameters = {}
     pool = _io_pool(len(paths), num_processes)
     done, saving = {}, collections.deque()
+    if pool is not None and not _CACHE:         # (nothing has used the GPU yet: pay its first-use costs while the images are read)
+        start_gpu_warmup()
 
     def unreadable(path, e):        # the reference swallows and logs every per-image failure (:960-964)
         log.error("cannot read %s", path, exc_info=(type(e), e, e.__traceback__))
@@ -1220,6 +1278,7 @@ def image_batch(image_paths, find_peptides_parameters=None, timestamp_epoch=None
     # (round 3 built the dicts here and pickled every one of them into a worker's pipe: 57 images/s).
     for shape, members in _windows(paths, unreadable, pool):
         err, rec, counts, fmt = None, None, None, N.PIXELS_U16
+        _join_gpu_warmup()
         try:
             _check_find_peptides_parameters(find_peptides_parameters)
             rec, counts, fmt = find_peptides_records(np.stack([a for _, _, a in members]), **find_peptides_parameters)
@@ -1242,6 +1301,7 @@ def image_batch(image_paths, find_peptides_parameters=None, timestamp_epoch=None
                 reap(0)
         del rec, members
     reap(0)
+    _join_gpu_warmup()
     return {ap: done[ap] for ap in paths if ap in done}
 
 
