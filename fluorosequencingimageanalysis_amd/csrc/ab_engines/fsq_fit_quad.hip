@@ -1,13 +1,13 @@
-// fsq_fit_quad.hip - K3/K4 production path: quad-cooperative LM fit (see fsq_lm_quad.h) in three kernels
+// fsq_fit_quad.hip - A/B engine (FSQ_ENGINE_QUAD): the quad-cooperative LM fit (see ../fsq_lm_quad.h) as one persistent launch, in three kernels
 //   k3_prep    per candidate: median / max / mean of the 5x5 ROI (start values of pflib.py:199-213)
 //   k3_quad    persistent, 4 lanes per fit, work queue with refill: the LM solve (mpfit.py:600-1388)
 //   k3_finish  per candidate: fit image, r_2, rmse, illumina_s_n, image coordinates (pflib.py:461-475)
-// A/B build only (make AB=1): the shipped library carries the rounds engine (fsq_fit_rounds.hip) alone.
+// A/B build only (make ab): the shipped library carries the rounds engine (fsq_fit_rounds.hip) alone.
 #ifdef FSQ_BUILD_AB
 #include <atomic>
 
-#include "fsq_common.h"
-#include "fsq_lm_quad.h"
+#include "../fsq_common.h"
+#include "../fsq_lm_quad.h"
 
 namespace {
 
