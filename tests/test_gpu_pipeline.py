@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from _util import FIELD_NAMES, bits_equal, load_field
+from _util import FIELD_NAMES, PARAM_NAMES, bits_equal, golden_params, load_field
 
 pytestmark = pytest.mark.gpu
 
@@ -85,6 +85,25 @@ def test_nondefault_parameters(env):
         r = rows[keep]
         exp = np.stack([r[k] for k in ("h0", "w0", "H", "A", "sigma_h", "sigma_w", "theta")], axis=1)
         assert bits_equal(got, exp).all()
+
+
+@pytest.mark.parametrize("name", PARAM_NAMES)
+def test_nondefault_keywords_equal_reference(env, name):
+    """find_peptides with non-default median windows / correlation matrices / c_std / r_2 threshold / consolidation radius
+    against the reference's own recorded tables (tests/golden/params_*.npz, oracle/gen_golden.py --only params)."""
+    torch, pflib, engine, O = env
+    g, img = load_field(name, prefix="params_")
+    prm = golden_params(g)
+    det = {k: prm[k] for k in ("median_filter_size", "correlation_matrix", "c_std") if k in prm}
+    assert pflib._psf_candidates(img, **det) == [tuple(int(v) for v in hw) for hw in g["candidates"]]
+    d = pflib.find_peptides(img, **prm)
+    assert np.array_equal(np.array(list(d.keys()), dtype=np.int32).reshape(-1, 2), g["table_keys"].reshape(-1, 2))
+    vals = list(d.values())
+    assert bits_equal(np.array([[float(x) for x in v[:7]] for v in vals]).reshape(-1, 7), g["table7"].reshape(-1, 7)).all()
+    assert np.array_equal(np.array([v[7] for v in vals]).reshape(-1, 5, 5), g["table_sub"])
+    assert bits_equal(np.array([v[8] for v in vals]).reshape(-1, 5, 5), g["table_fit"]).all()
+    assert bits_equal(np.array([[float(v[9]), float(v[10]), float(v[11])] for v in vals]).reshape(-1, 3),
+                      g["table_metrics"].reshape(-1, 3)).all()
 
 
 def test_large_windows(env):

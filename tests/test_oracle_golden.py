@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 
 import oracle as O
-from _util import DEGEN_NAMES, FIELD_NAMES, GOLD, TEXTBOOK_NAMES, WIDE_NAMES, bits_equal, load_field, rois_of
+from _util import (DEGEN_NAMES, FIELD_NAMES, GOLD, PARAM_NAMES, TEXTBOOK_NAMES, WIDE_NAMES, bits_equal, golden_params, load_field,
+                   rois_of)
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -54,9 +55,12 @@ def test_find_peptides_table(name):
     assert bits_equal(fit, g["table_fit"]).all()
 
 
-def _check_against_golden(g, img, mode):
+def _check_against_golden(g, img, mode, prm=None):
     """candidates, every LM solve and the consolidated table of one fixture, bit for bit."""
-    assert np.array_equal(O.candidates(img), g["candidates"])
+    prm = prm or {}
+    det = dict(med_size=prm.get("median_filter_size", 5), K=prm.get("correlation_matrix", O.DEFAULT_K), c_std=prm.get("c_std", 2.0))
+    fp = dict(det, r2_thr=prm.get("r_2_threshold", 0.7), radius=prm.get("consolidation_radius", 4))
+    assert np.array_equal(O.candidates(img, **det), g["candidates"])
     f = O.fit_rois(rois_of(img, g["candidates"]), mode=mode, n_threads=os.cpu_count())
     assert bits_equal(f["p"], g["params"]).all()
     for k in ("status", "niter", "nfev"):
@@ -64,9 +68,9 @@ def _check_against_golden(g, img, mode):
     assert bits_equal(f["fnorm"], g["fnorm"]).all()
     if int(g["table_error"]):
         with pytest.raises(AssertionError):
-            O.find_peptides(img, mode=mode, n_threads=os.cpu_count())
+            O.find_peptides(img, mode=mode, n_threads=os.cpu_count(), **fp)
         return
-    rows, fits, keep, key = O.find_peptides(img, mode=mode, n_threads=os.cpu_count())
+    rows, fits, keep, key = O.find_peptides(img, mode=mode, n_threads=os.cpu_count(), **fp)
     assert np.array_equal(key, g["table_keys"].reshape(-1, 2))
     r = rows[keep]
     got7 = np.stack([r[k] for k in ("h0", "w0", "H", "A", "sigma_h", "sigma_w", "theta")], axis=1)
@@ -84,6 +88,16 @@ def test_degenerate_frames_match_reference(name):
     none of these frames drives a step non-finite, status -16, mpfit.py:1330-1335.)"""
     g, img = load_field(name, prefix="degen_")
     _check_against_golden(g, img, mode=0)
+
+
+@pytest.mark.parametrize("name", PARAM_NAMES)
+def test_nondefault_keywords_match_reference(name):
+    """find_peptides with other median windows (3, 4, 7, 9), correlation matrices (3 x 3, 7 x 7, 11 x 11), c_std, r_2 thresholds
+    and consolidation radii (2, 3, 6, 9) through the unmodified reference (oracle/gen_golden.py --only params)."""
+    g, img = load_field(name, prefix="params_")
+    prm = golden_params(g)
+    assert prm and int(g["table_error"]) == 0 and len(g["table_keys"]) > 5
+    _check_against_golden(g, img, mode=0, prm=prm)
 
 
 @pytest.mark.parametrize("name", WIDE_NAMES)
