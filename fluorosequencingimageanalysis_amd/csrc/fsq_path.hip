@@ -11,6 +11,7 @@
 namespace {
 
 constexpr int REC_WORDS = FSQ_PEAK_RECORD_BYTES / 2;      // a record is 189 16-bit words: 64 (row) + 100 (fit_img) + 25 (sub_img)
+constexpr int REC_WORDS_U32 = FSQ_PEAK_RECORD_BYTES_U32 / 2;   // FSQ_PIXELS_U32: 214 words, sub_img as 25 uint32
 
 size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -38,21 +39,25 @@ PathLayout path_layout(int n_fields, int H, int W, int64_t cand_cap, int64_t rec
 }
 
 // record r = row (64 words) | fit_img (100 words) | the ROI's 25 pixel words as they sit in the image
+// (WIDE: the image holds uint32 pixels, two record words each)
+template <bool WIDE>
 __global__ void __launch_bounds__(256) k_pack_records(const FsqRow* __restrict__ table, const double* __restrict__ fit,
                                                       const uint16_t* __restrict__ img, int H, int W, long long k,
                                                       uint16_t* __restrict__ out)
 {
+    constexpr int RW = WIDE ? REC_WORDS_U32 : REC_WORDS;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= k * REC_WORDS) return;
-    const long long r = t / REC_WORDS;
-    const int wd = (int)(t - r * REC_WORDS);
+    if (t >= k * RW) return;
+    const long long r = t / RW;
+    const int wd = (int)(t - r * RW);
     uint16_t v;
     if (wd < 64) v = ((const uint16_t*)(table + r))[wd];
     else if (wd < 164) v = ((const uint16_t*)(fit + r * 25))[wd - 64];
     else {
-        const int p = wd - 164, a = p / 5, b = p - 5 * a;
+        const int q = wd - 164, p = WIDE ? q >> 1 : q, a = p / 5, b = p - 5 * a;
         const FsqRow& R = table[r];
-        v = img[((size_t)R.field * H + (R.h - 2 + a)) * W + (R.w - 2 + b)];
+        const size_t at = ((size_t)R.field * H + (R.h - 2 + a)) * W + (R.w - 2 + b);
+        v = WIDE ? img[2 * at + (q & 1)] : img[at];
     }
     out[t] = v;
 }
@@ -97,7 +102,8 @@ extern "C" int fsq_find_peptides(const void* d_img, int n_fields, int H, int W, 
     if (total < 0) return FSQ_ENOTIMPL;                 // a response image sums to >= 2^53 (see fsq_detect)
     if (n_candidates) *n_candidates = total;
     if (total > cand_cap) return FSQ_ERANGE;            // (counts are complete: call again with cand_cap >= *n_candidates)
-    const int fmode = (mode & 0xff) | (prm->pixel_format == FSQ_PIXELS_F16 ? FSQ_PIXELS_F16_FLAG : 0);
+    const bool wide = prm->pixel_format == FSQ_PIXELS_U32;
+    const int fmode = (mode & 0xff) | (prm->pixel_format == FSQ_PIXELS_F16 ? FSQ_PIXELS_F16_FLAG : 0) | (wide ? FSQ_PIXELS_U32_FLAG : 0);
     rc = fsq_fit_candidates((const uint16_t*)d_img, n_fields, H, W, cand, total, fmode, rows, ws + L.fitws, (int64_t)(L.total - L.fitws), stream);
     if (rc != FSQ_OK) return rc;
     rc = fsq_consolidate(rows, counts, offsets, n_fields, H, W, r2_threshold, radius, py2_round, keep, d_nkeep, ws + L.stage,
@@ -114,9 +120,11 @@ extern "C" int fsq_find_peptides(const void* d_img, int n_fields, int H, int W, 
     if (kept > 0) {
         rc = fsq_fit_images(table, nullptr, kept, fit, stream);
         if (rc != FSQ_OK) return rc;
-        const long long words = (long long)kept * REC_WORDS;
-        hipLaunchKernelGGL(k_pack_records, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, table, fit, (const uint16_t*)d_img,
-                           H, W, (long long)kept, (uint16_t*)d_records);
+        const long long words = (long long)kept * (wide ? REC_WORDS_U32 : REC_WORDS);
+        if (wide) hipLaunchKernelGGL(k_pack_records<true>, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, table, fit, (const uint16_t*)d_img,
+                                     H, W, (long long)kept, (uint16_t*)d_records);
+        else hipLaunchKernelGGL(k_pack_records<false>, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, table, fit, (const uint16_t*)d_img,
+                                H, W, (long long)kept, (uint16_t*)d_records);
         FSQ_HIP_CHECK(hipGetLastError());
     }
     return FSQ_OK;

@@ -16,7 +16,8 @@
 #include <stdint.h>
 #include <string.h>
 
-#define REC_BYTES 378
+#define REC_BYTES_16 378                /* FSQ_PEAK_RECORD_BYTES */
+#define REC_BYTES_32 428                /* FSQ_PEAK_RECORD_BYTES_U32: sub_img as 25 uint32 words */
 /* byte offsets inside a record: the FsqRow of include/fsq.h, then fit_img double[25], then the 25 pixel words of sub_img */
 enum { O_H0 = 0, O_W0 = 8, O_HH = 16, O_A = 24, O_SH = 32, O_SW = 40, O_TH = 48, O_RMSE = 56, O_R2 = 64, O_SN = 72,
        O_KEYH = 120, O_KEYW = 124, O_FIT = 128, O_SUB = 328 };
@@ -60,9 +61,11 @@ static PyObject* view5x5(PyArrayObject* block, Py_ssize_t i)
     return v;
 }
 
-/* one field: records [a, b) -> dict */
-static PyObject* field_dict(const unsigned char* rec, Py_ssize_t a, Py_ssize_t b, int f16)
+/* one field: records [a, b) -> dict.  fmt: the pixel format of include/fsq.h (0 uint16, 1 binary16, 2 uint32) */
+static PyObject* field_dict(const unsigned char* rec, Py_ssize_t a, Py_ssize_t b, int fmt)
 {
+    const int f16 = (fmt == 1);
+    const Py_ssize_t REC_BYTES = (fmt == 2) ? REC_BYTES_32 : REC_BYTES_16;
     const Py_ssize_t m = b - a;
 #if PY_VERSION_HEX < 0x030d0000
     PyObject* d = m > 5 ? _PyDict_NewPresized(m) : PyDict_New();     /* (no rehashing while the field's peaks are inserted) */
@@ -80,7 +83,10 @@ static PyObject* field_dict(const unsigned char* rec, Py_ssize_t a, Py_ssize_t b
         for (Py_ssize_t i = 0; i < m; i++) {
             const unsigned char* r = rec + (a + i) * REC_BYTES;
             memcpy(pf + i * 25, r + O_FIT, 200);
-            for (int k = 0; k < 25; k++) { uint16_t w; memcpy(&w, r + O_SUB + 2 * k, 2); ps[i * 25 + k] = pixel_value(w, f16); }
+            if (fmt == 2)
+                for (int k = 0; k < 25; k++) { uint32_t w; memcpy(&w, r + O_SUB + 4 * k, 4); ps[i * 25 + k] = (int64_t)w; }
+            else
+                for (int k = 0; k < 25; k++) { uint16_t w; memcpy(&w, r + O_SUB + 2 * k, 2); ps[i * 25 + k] = pixel_value(w, f16); }
         }
     }
     for (Py_ssize_t i = 0; i < m; i++) {
@@ -115,18 +121,20 @@ fail:
     return NULL;
 }
 
-/* fields_to_dicts(records, offsets, first_field, last_field, f16) -> list of dicts for fields first_field .. last_field - 1
- *   records  a C-contiguous buffer of k x 378 bytes;  offsets  int64 buffer, offsets[f] .. offsets[f + 1] = field f's records */
+/* fields_to_dicts(records, offsets, first_field, last_field, pixel_format) -> list of dicts for fields first_field .. last_field - 1
+ *   records  a C-contiguous buffer of k x 378 bytes (428 for pixel format 2);  offsets  int64 buffer, offsets[f] .. offsets[f + 1] =
+ *   field f's records */
 static PyObject* fields_to_dicts(PyObject* self, PyObject* args)
 {
     Py_buffer rec, offs;
     Py_ssize_t f0, f1;
-    int f16;
-    if (!PyArg_ParseTuple(args, "y*y*nnp", &rec, &offs, &f0, &f1, &f16)) return NULL;
+    int fmt;
+    if (!PyArg_ParseTuple(args, "y*y*nni", &rec, &offs, &f0, &f1, &fmt)) return NULL;
     PyObject* out = NULL;
+    const Py_ssize_t REC_BYTES = (fmt == 2) ? REC_BYTES_32 : REC_BYTES_16;
     const Py_ssize_t nrec = rec.len / REC_BYTES, noff = offs.len / 8;
     const int64_t* o = (const int64_t*)offs.buf;
-    if (rec.len % REC_BYTES || offs.len % 8 || f0 < 0 || f1 < f0 || f1 + 1 > noff) {
+    if (fmt < 0 || fmt > 2 || rec.len % REC_BYTES || offs.len % 8 || f0 < 0 || f1 < f0 || f1 + 1 > noff) {
         PyErr_SetString(PyExc_ValueError, "fields_to_dicts: bad buffer sizes / field range");
         goto done;
     }
@@ -138,7 +146,7 @@ static PyObject* fields_to_dicts(PyObject* self, PyObject* args)
     out = PyList_New(f1 - f0);
     if (!out) goto done;
     for (Py_ssize_t f = f0; f < f1; f++) {
-        PyObject* d = field_dict((const unsigned char*)rec.buf, (Py_ssize_t)o[f], (Py_ssize_t)o[f + 1], f16);
+        PyObject* d = field_dict((const unsigned char*)rec.buf, (Py_ssize_t)o[f], (Py_ssize_t)o[f + 1], fmt);
         if (!d) { Py_CLEAR(out); goto done; }
         PyList_SET_ITEM(out, f - f0, d);
     }

@@ -128,8 +128,23 @@ RECORD_DTYPE = np.dtype({"names": list(N.ROW_DTYPE.names) + ["fit", "sub"],
                          "itemsize": PEAK_RECORD_BYTES})
 
 
-def peak_record_view(rec):
-    """uint8[k, PEAK_RECORD_BYTES] (host, C-contiguous) -> RECORD_DTYPE[k] view of the same memory (no copy)."""
+#: the record of PIXELS_U32 frames (fsq_find_peptides with uint32 pixels): sub_img as 25 uint32 words, 428 bytes
+PEAK_RECORD_BYTES_U32 = 128 + 200 + 100
+RECORD_DTYPE_U32 = np.dtype({"names": list(N.ROW_DTYPE.names) + ["fit", "sub"],
+                             "formats": [N.ROW_DTYPE.fields[k][0] for k in N.ROW_DTYPE.names] + [("<f8", (5, 5)), ("<u4", (5, 5))],
+                             "offsets": [N.ROW_DTYPE.fields[k][1] for k in N.ROW_DTYPE.names] + [128, 328],
+                             "itemsize": PEAK_RECORD_BYTES_U32})
+
+
+def peak_record_bytes(pixel_format=N.PIXELS_U16):
+    return PEAK_RECORD_BYTES_U32 if pixel_format == N.PIXELS_U32 else PEAK_RECORD_BYTES
+
+
+def peak_record_view(rec, pixel_format=N.PIXELS_U16):
+    """uint8[k, peak_record_bytes(pixel_format)] (host, C-contiguous) -> RECORD_DTYPE[k] (RECORD_DTYPE_U32 for PIXELS_U32)
+    view of the same memory (no copy)."""
+    if pixel_format == N.PIXELS_U32:
+        return np.ascontiguousarray(rec).reshape(-1, PEAK_RECORD_BYTES_U32).view(RECORD_DTYPE_U32).reshape(-1)
     return np.ascontiguousarray(rec).reshape(-1, PEAK_RECORD_BYTES).view(RECORD_DTYPE).reshape(-1)
 
 
@@ -147,9 +162,11 @@ class PathRunner:
     library call on the current stream, with its own workspace: no interpreter between the stages (the calling thread holds
     the interpreter lock only to make the call).  Buffers grow on demand (FSQ_ERANGE tells by how much)."""
 
-    def __init__(self, n_fields, H, W, device=None, cand_cap=None, record_cap=None):
+    def __init__(self, n_fields, H, W, device=None, cand_cap=None, record_cap=None, record_bytes=PEAK_RECORD_BYTES):
+        """record_bytes: PEAK_RECORD_BYTES, or PEAK_RECORD_BYTES_U32 for a runner that is handed PIXELS_U32 frames."""
         torch = _torch()
         self.torch = torch
+        self.record_bytes = int(record_bytes)
         self.dev = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
         self.L = N.lib()
         self.n_fields, self.H, self.W = int(n_fields), int(H), int(W)
@@ -166,7 +183,7 @@ class PathRunner:
         self.ws = None
         self.records = None
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
-        self.records = torch.empty((self.record_cap, PEAK_RECORD_BYTES), dtype=torch.uint8, device=self.dev)
+        self.records = torch.empty((self.record_cap, self.record_bytes), dtype=torch.uint8, device=self.dev)
 
     def run(self, d_img, prm, r2_threshold=0.7, radius=4, mode=N.MODE_REF, py2_round=True):
         """-> (records uint8[k, PEAK_RECORD_BYTES] - a view of this runner's buffer, valid until its next run -, offsets int32[n + 1],
@@ -175,6 +192,8 @@ class PathRunner:
         n_fields = int(d_img.shape[0])              # (any number of fields up to the capacity the runner was built for)
         if not (1 <= n_fields <= self.n_fields) or tuple(d_img.shape[1:]) != (self.H, self.W):
             raise ValueError("d_img must hold 1 .. %d fields of %d x %d" % (self.n_fields, self.H, self.W))
+        if peak_record_bytes(prm.pixel_format) != self.record_bytes or d_img.element_size() != (4 if prm.pixel_format == N.PIXELS_U32 else 2):
+            raise ValueError("pixel format %d does not match this runner's record size / the image's word size" % prm.pixel_format)
         while True:
             rc = self.L.fsq_find_peptides(d_img.data_ptr(), n_fields, self.H, self.W, ctypes.byref(prm), float(r2_threshold),
                                           int(radius), 1 if py2_round else 0, int(mode), self.cand_cap, self.records.data_ptr(),

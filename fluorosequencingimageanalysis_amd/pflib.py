@@ -167,12 +167,13 @@ def _records_to_dicts(rows, fit, sub, offs, failed=(), pixel_format=N.PIXELS_U16
     With the records themselves (fit and sub None, engine.peak_record_view) the C builder does it, a few fields per call so
     that other threads get the interpreter in between; _records_to_dicts_py is the same in Python (and what the C builder
     is tested against)."""
-    if fit is not None or _fsq_pyhost is None or rows.dtype != _engine.RECORD_DTYPE or not rows.flags.c_contiguous:
+    if (fit is not None or _fsq_pyhost is None or not rows.flags.c_contiguous
+            or rows.dtype != (_engine.RECORD_DTYPE_U32 if pixel_format == N.PIXELS_U32 else _engine.RECORD_DTYPE)):
         return _records_to_dicts_py(rows, fit, sub, offs, failed, pixel_format)
     was_enabled = gc.isenabled()
     gc.disable()                        # (millions of fresh containers, none of them cyclic)
     try:
-        raw = rows.view(np.uint8).reshape(-1, _engine.PEAK_RECORD_BYTES)
+        raw = rows.view(np.uint8).reshape(-1, _engine.peak_record_bytes(pixel_format))
         o = np.ascontiguousarray(offs, dtype=np.int64)
         n_fields = len(o) - 1
         out = []
@@ -181,7 +182,7 @@ def _records_to_dicts(rows, fit, sub, offs, failed=(), pixel_format=N.PIXELS_U16
             f1 = f0 + 1
             while f1 < n_fields and o[f1 + 1] - o[f0] <= DICT_SLICE_PEAKS:
                 f1 += 1
-            out.extend(_fsq_pyhost.fields_to_dicts(raw, o, f0, f1, pixel_format == N.PIXELS_F16))
+            out.extend(_fsq_pyhost.fields_to_dicts(raw, o, f0, f1, int(pixel_format)))
             f0 = f1
         for f in failed:
             out[f] = AssertionError("field %d: re-keyed peak collides with an existing key (pflib.py:518)" % f)
@@ -248,33 +249,21 @@ def _engine_dicts(eng, d_img, pixel_format=N.PIXELS_U16):
     return _records_to_dicts(rows, fit, sub, offs.cpu().numpy(), failed)
 
 
-def _wide_pass(imgs, prm, r_2_threshold, radius, mode):
-    """find_peptides of a PIXELS_U32 stack (pixel values beyond 16 bits): stand-alone Engine passes (detect -> fit ->
-    consolidate on 32-bit pixels) over slices of the stack; sub_img is cut from the host copy.  The streaming pipeline
-    (fit queue, 378-byte peak records) carries 16-bit pixels only, so this path trades its overlap for generality."""
-    if mode == N.MODE_TEXTBOOK_F32:
-        raise NotImplementedError("solver='textbook_f32' takes 16-bit pixels only")
-    n, H, W = imgs.shape
-    per = max(1, min(n, CHUNK_PIXELS // (H * W)))
-    eng = _cached(("wide", _device_key(), per, H, W), lambda: _engine.Engine(per, H, W))
-    out = []
+def _wide_pass(eng, imgs, prm, r_2_threshold, radius, mode):
+    """find_peptides of a PIXELS_U32 stack on a caller-owned Engine: one stand-alone pass (detect -> fit -> consolidate on 32-bit
+    pixels), the kept table and fit images copied back, sub_img cut from the host copy (pflib.py:443)."""
+    if len(imgs) != eng.n_fields or imgs.shape[1:] != (eng.H, eng.W):
+        raise ValueError("the Engine was built for %d fields of %d x %d" % (eng.n_fields, eng.H, eng.W))
     d = np.arange(-2, 3)
-    with _CACHE_LOCK:
-        for f0 in range(0, n, per):
-            part = imgs[f0:f0 + per]
-            if len(part) < per:                     # (the Engine's shape is fixed: pad the last slice with copies of its first field)
-                part = np.concatenate([part, np.repeat(part[:1], per - len(part), axis=0)])
-            d_img = _engine.to_device_pixels(part, N.PIXELS_U32)
-            eng.run(d_img, prm, r_2_threshold, radius, mode, PY2_ROUND)
-            nkeep = eng.nkeep.cpu().numpy()
-            table, offs = eng.kept_table()
-            fit = eng.fit_images(table).cpu().numpy().reshape(-1, 5, 5)
-            rows = table.cpu().numpy().view(N.ROW_DTYPE).reshape(-1)
-            sub = part[rows["field"][:, None, None], (rows["h"][:, None] + d)[:, :, None],
-                       (rows["w"][:, None] + d)[:, None, :]].astype(np.int64)            # pflib.py:443
-            failed = set(int(f) for f in np.nonzero(nkeep[:per] < 0)[0])
-            out.extend(_records_to_dicts(rows, fit, sub, offs.cpu().numpy(), failed)[:min(per, n - f0)])
-    return out
+    d_img = _engine.to_device_pixels(imgs, N.PIXELS_U32)
+    eng.run(d_img, prm, r_2_threshold, radius, mode, PY2_ROUND)
+    nkeep = eng.nkeep.cpu().numpy()
+    table, offs = eng.kept_table()
+    fit = eng.fit_images(table).cpu().numpy().reshape(-1, 5, 5)
+    rows = table.cpu().numpy().view(N.ROW_DTYPE).reshape(-1)
+    sub = imgs[rows["field"][:, None, None], (rows["h"][:, None] + d)[:, :, None], (rows["w"][:, None] + d)[:, None, :]].astype(np.int64)
+    failed = set(int(f) for f in np.nonzero(nkeep[:eng.n_fields] < 0)[0])
+    return _records_to_dicts(rows, fit, sub, offs.cpu().numpy(), failed)
 
 
 #: find_peptides_batch streams a stack through the GPU in chunks of about this many pixels (engine.StreamPipeline)
@@ -340,17 +329,21 @@ class _BatchRunner:
     ~10 % slower on the GPU, but the chunks complete evenly spaced, and the 0.23 s the interpreter needs to build 490 000
     12-tuples overlap the fitting instead of following it (1 024 fields: 0.60 s -> 0.45 s)."""
 
-    def __init__(self, per, H, W, mode=N.MODE_REF):
+    def __init__(self, per, H, W, mode=N.MODE_REF, wide=False):
+        """wide: the runner of PIXELS_U32 stacks (uint32 staging buffers, 428-byte records); such stacks always take the lanes
+        (the fit queue of the continuous-batching pipeline carries 16-bit pixels)."""
         torch = _engine._torch()
         self.torch = torch
         self.per, self.H, self.W = int(per), int(H), int(W)
         self.dev = torch.device("cuda", torch.cuda.current_device())
         self.mode = mode
+        self.wide = bool(wide)
+        self.rec_bytes = _engine.PEAK_RECORD_BYTES_U32 if self.wide else _engine.PEAK_RECORD_BYTES
         self.pipe = None                        # (both built on first use)
         self.lane_engines = self.lane_streams = None
         # four staging buffers: the stager runs at most two chunks ahead of the pipeline thread (queue of 2), so the buffer of
         # chunk c is written again (chunk c + 4) only after the pipeline thread has recorded the upload event of chunk c
-        self.pin = [torch.empty((self.per, H, W), dtype=torch.int16).pin_memory() for _ in range(4)]
+        self.pin = [torch.empty((self.per, H, W), dtype=torch.int32 if self.wide else torch.int16).pin_memory() for _ in range(4)]
         self.pin_ev = [None] * 4
         self.pin_free = [threading.Event() for _ in range(4)]   # set: the chunk staged in the buffer has been handed to the GPU
         for e in self.pin_free:
@@ -378,6 +371,8 @@ class _BatchRunner:
         import sys
         torch, per = self.torch, self.per
         n_lanes = 0 if (raw or self.mode == N.MODE_TEXTBOOK_F32) else int(os.environ.get("FSQ_BATCH_LANES", DICT_LANES))
+        if self.wide != (fmt == N.PIXELS_U32) or (self.wide and n_lanes <= 0):
+            raise NotImplementedError("pixel values beyond 16 bits go through the dict-building lanes only")
         n = len(words)
         if n_lanes > 0:
             # lanes take chunks of any size up to `per`: the first ones are small so that the first records - and with them the
@@ -436,7 +431,7 @@ class _BatchRunner:
                             m, kk = sizes[c], int(rec.shape[0])
                             j = self.land_free.get()
                             if self.land_rec[j] is None or self.land_rec[j].shape[0] < kk:
-                                self.land_rec[j] = torch.empty((kk + kk // 4 + 1024, _engine.PEAK_RECORD_BYTES), dtype=torch.uint8).pin_memory()
+                                self.land_rec[j] = torch.empty((kk + kk // 4 + 1024, self.rec_bytes), dtype=torch.uint8).pin_memory()
                             if self.land_meta[j] is None or self.land_meta[j].shape[0] < 2 * per + 2:
                                 self.land_meta[j] = torch.empty(2 * per + 2, dtype=torch.int32).pin_memory()
                             self.land_rec[j][:kk].copy_(rec, non_blocking=True)
@@ -480,7 +475,7 @@ class _BatchRunner:
                     self.pin_free[i].clear()
                     if self.pin_ev[i] is not None:
                         self.pin_ev[i].synchronize()        # (... and the upload is done)
-                    host = self.pin[i].numpy().view(np.uint16)
+                    host = self.pin[i].numpy().view(np.uint32 if self.wide else np.uint16)
                     host[:len(part)] = part
                     if len(part) < per and n_lanes == 0:    # (pipeline engines have a fixed field count: the last chunk is filled up with copies of its last field)
                         host[len(part):] = part[-1]
@@ -532,7 +527,7 @@ class _BatchRunner:
                 meta = self.land_meta[j][:2 * m + 1].numpy()
                 nk, offs = meta[:m].copy(), meta[m:].copy()
                 failed = set(int(f) for f in np.nonzero(nk < 0)[0])
-                dicts = _records_to_dicts(_engine.peak_record_view(self.land_rec[j][:kk].numpy()), None, None, offs, failed, fmt)
+                dicts = _records_to_dicts(_engine.peak_record_view(self.land_rec[j][:kk].numpy(), fmt), None, None, offs, failed, fmt)
             finally:
                 self.land_free.put(j)
             out[first[c]:first[c + 1]] = dicts
@@ -556,7 +551,8 @@ class _BatchRunner:
             for j in range(n_lanes + 2):
                 self.land_free.put(j)
             if n_lanes > 0 and (self.lane_engines is None or len(self.lane_engines) != n_lanes):
-                self.lane_engines = [_engine.PathRunner(self.per, self.H, self.W, device=self.dev) for _ in range(n_lanes)]
+                self.lane_engines = [_engine.PathRunner(self.per, self.H, self.W, device=self.dev, record_bytes=self.rec_bytes)
+                                     for _ in range(n_lanes)]
                 self.lane_streams = [torch.cuda.Stream(device=self.dev) for _ in range(n_lanes)]
                 self.land_rec = [None] * (n_lanes + 2)      # pinned landing buffers of the chunks' records / counts
                 self.land_meta = [None] * (n_lanes + 2)
@@ -636,12 +632,11 @@ def find_peptides_batch(images, median_filter_size=5, correlation_matrix=default
         return []
     if H < 5 or W < 5:              # (no candidates: pflib.py:252)
         return [{} for _ in range(n)]
-    if fmt == N.PIXELS_U32:                                 # pixel values beyond 16 bits
-        if engine is not None:
-            raise NotImplementedError("a caller-owned Engine takes 16-bit pixels")
-        out = _wide_pass(imgs, prm, r_2_threshold, consolidation_radius, mode)
-        if on_chunk is not None:
-            on_chunk(0, out)
+    wide = fmt == N.PIXELS_U32                              # pixel values beyond 16 bits: uint32 words, 428-byte records
+    if wide and mode == N.MODE_TEXTBOOK_F32:
+        raise NotImplementedError("solver='textbook_f32' takes 16-bit pixels only")
+    if wide and engine is not None:
+        out = _wide_pass(engine, imgs, prm, r_2_threshold, consolidation_radius, mode)
     elif engine is not None:                                # (a caller-owned Engine: one stand-alone pass)
         d_img = _engine.to_device_u16(imgs)
         engine.run(d_img, prm, r_2_threshold, consolidation_radius, mode, PY2_ROUND)
@@ -649,7 +644,7 @@ def find_peptides_batch(images, median_filter_size=5, correlation_matrix=default
     else:
         n_chunks = max(1, -(-(n * H * W) // CHUNK_PIXELS))
         per = -(-n // n_chunks)
-        out = _run_cached_runner(("batch", _device_key(), per, H, W, mode), lambda: _BatchRunner(per, H, W, mode),
+        out = _run_cached_runner(("batch", _device_key(), per, H, W, mode, wide), lambda: _BatchRunner(per, H, W, mode, wide),
                                  imgs, fmt, prm, r_2_threshold, consolidation_radius, on_chunk)
     if errors == 'raise':
         for d in out:
@@ -685,7 +680,7 @@ def find_peptides_records(images, median_filter_size=5, correlation_matrix=defau
         return np.zeros((0, _engine.PEAK_RECORD_BYTES), np.uint8), np.zeros(n, np.int32), fmt
     n_chunks = max(1, -(-(n * H * W) // CHUNK_PIXELS))
     per = -(-n // n_chunks)
-    rec, counts = _run_cached_runner(("batch", _device_key(), per, H, W, mode), lambda: _BatchRunner(per, H, W, mode),
+    rec, counts = _run_cached_runner(("batch", _device_key(), per, H, W, mode, False), lambda: _BatchRunner(per, H, W, mode),
                                      imgs, fmt, prm, r_2_threshold, consolidation_radius, raw=True, device=bool(device))
     return rec, counts, fmt
 
@@ -695,7 +690,7 @@ def records_to_dicts(records, counts, pixel_format=N.PIXELS_U16):
     counts = np.asarray(counts).reshape(-1)
     failed = set(int(k) for k in np.nonzero(counts < 0)[0])
     offs = np.concatenate([[0], np.cumsum(np.maximum(counts, 0))])
-    return _records_to_dicts(_engine.peak_record_view(records), None, None, offs, failed, pixel_format)
+    return _records_to_dicts(_engine.peak_record_view(records, pixel_format), None, None, offs, failed, pixel_format)
 
 
 def count_candidates(images, median_filter_size=5, correlation_matrix=default_correlation_matrix, c_std=2, **unused):

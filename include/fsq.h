@@ -71,9 +71,10 @@ typedef struct FsqRow {
 #define FSQ_PIXELS_U16 0
 #define FSQ_PIXELS_F16 1
 #define FSQ_PIXELS_U32 2   /* round 4: uint32 pixels (values < 2^31) for images beyond 16 bits - the reference computes on int64 whatever it
-                            * is handed.  Taken by fsq_detect, fsq_fit_candidates (| FSQ_PIXELS_U32_FLAG) and fsq_fit_images / fsq_consolidate /
-                            * fsq_kept_rows (format-independent); the fit queue (fsq_fitq_*), fsq_find_peptides' 378-byte records, the
-                            * single-precision mode and the photometry / tracking entry points stay 16-bit (FSQ_ENOTIMPL / uint16 arguments). */
+                            * is handed.  Taken by fsq_detect, fsq_fit_candidates (| FSQ_PIXELS_U32_FLAG), fsq_find_peptides (records of
+                            * FSQ_PEAK_RECORD_BYTES_U32 bytes) and fsq_fit_images / fsq_consolidate / fsq_kept_rows (format-independent);
+                            * the fit queue (fsq_fitq_*), the single-precision mode and the photometry / tracking entry points stay 16-bit
+                            * (FSQ_ENOTIMPL / uint16 arguments). */
 
 #define FSQ_MAX_KSIZE 15                           /* largest correlation matrix / median window side (round 4: was 9) */
 typedef struct FsqDetectParams {
@@ -205,7 +206,7 @@ int fsq_kept_rows(const FsqRow* d_rows, const int32_t* d_keep, const int32_t* d_
  *   d_img              uint16 / binary16 [n_fields][H][W] (prm->pixel_format)
  *   mode               FSQ_MODE_REF / FSQ_MODE_TEXTBOOK / FSQ_MODE_TEXTBOOK_F32
  *   cand_cap           candidates the workspace is sized for (all fields together)
- *   d_records          uint8[record_cap][FSQ_PEAK_RECORD_BYTES] out, fields in order, a field's peaks in the reference's dict
+ *   d_records          uint8[record_cap][FSQ_PEAK_RECORD_BYTES] (FSQ_PEAK_RECORD_BYTES_U32 for uint32 pixels) out, fields in order, a field's peaks in the reference's dict
  *                      order: bytes 0..127 the FsqRow, 128..327 fit_img double[25] (gaussfitter.py:253), 328..377 the 25
  *                      16-bit pixel words of sub_img as they sit in d_img (pflib.py:443)
  *   d_record_offsets   int32[n_fields + 1] out: field f's records are [offsets[f], offsets[f + 1])
@@ -217,6 +218,7 @@ int fsq_kept_rows(const FsqRow* d_rows, const int32_t* d_keep, const int32_t* d_
  * the following launches); the records themselves are complete when the work enqueued on `stream` is.
  */
 #define FSQ_PEAK_RECORD_BYTES 378
+#define FSQ_PEAK_RECORD_BYTES_U32 428   /* prm->pixel_format == FSQ_PIXELS_U32: the same record with sub_img as 25 uint32 words */
 int64_t fsq_find_peptides_workspace_bytes(int n_fields, int H, int W, int64_t cand_cap, int64_t record_cap);
 int fsq_find_peptides(const void* d_img, int n_fields, int H, int W, const FsqDetectParams* prm, double r2_threshold,
                       int radius, int py2_round, int mode, int64_t cand_cap, void* d_records, int64_t record_cap,

@@ -110,6 +110,29 @@ def test_stack_equals_oracle(env):
     assert n_peaks > 300
 
 
+def test_whole_path_in_one_call_and_caller_owned_engine(env):
+    """fsq_find_peptides with uint32 pixels (engine.PathRunner: 428-byte records, sub_img as uint32 words) and the caller-owned
+    Engine of find_peptides_batch(engine=...) give the dicts of the default route."""
+    torch, N, E, pflib, synth, O = env
+    imgs = _wide_stack(synth, range(400, 406), (96, 112), 20)
+    ref = pflib.find_peptides_batch(imgs, errors='return')
+    prm = E.detect_params(5, pflib.default_correlation_matrix, 2, N.PIXELS_U32, int(imgs.max()))
+    runner = E.PathRunner(6, 96, 112, record_bytes=E.PEAK_RECORD_BYTES_U32)
+    rec, offs, nk, ncand = runner.run(E.to_device_pixels(imgs, N.PIXELS_U32), prm)
+    torch.cuda.synchronize()
+    counts = np.where(nk.cpu().numpy()[:6] < 0, -1, np.diff(offs.cpu().numpy()))
+    got = pflib.records_to_dicts(rec.cpu().numpy(), counts, N.PIXELS_U32)
+    own = pflib.find_peptides_batch(imgs, engine=E.Engine(6, 96, 112), errors='return')
+    for a, b, c in zip(ref, got, own):
+        assert not isinstance(a, Exception) and list(a) == list(b) == list(c) and len(a) > 3
+        for k in a:
+            for x, y, z in zip(a[k], b[k], c[k]):
+                assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True) and np.array_equal(np.asarray(x), np.asarray(z), equal_nan=True)
+            assert a[k][7].dtype == b[k][7].dtype == c[k][7].dtype == np.int64 and int(a[k][7].max()) > 65535
+    with pytest.raises(ValueError):             # a 16-bit runner refuses 32-bit frames (and the other way round) instead of mis-reading them
+        E.PathRunner(6, 96, 112).run(E.to_device_pixels(imgs, N.PIXELS_U32), prm)
+
+
 def test_every_fit_equals_oracle(env):
     """All candidates' solves of wide frames (kept or not) vs the oracle: parameters, status, iteration and evaluation
     counts, and the metrics of the row."""

@@ -107,7 +107,7 @@ def test_product_does_not_import_oracle():
 def test_c_dict_builder_equals_python_builder():
     """csrc/fsq_pyhost.c (peak records -> the reference's dicts) against the Python builder on synthetic records: keys, order,
     value types (numpy.float64 scalars, a Python float for rmse, int64 / float64 5x5 views of one block per field), NaN metrics,
-    empty fields, failed fields, float16 pixel words."""
+    empty fields, failed fields, float16 pixel words, the 428-byte records of uint32 pixels."""
     from fluorosequencingimageanalysis_amd import _native as N, engine as E, pflib
     if pflib._fsq_pyhost is None:           # (a fresh tree: build it like the library)
         import importlib
@@ -116,16 +116,17 @@ def test_c_dict_builder_equals_python_builder():
         pflib._fsq_pyhost = importlib.import_module("fluorosequencingimageanalysis_amd._fsq_pyhost")
     rng = np.random.default_rng(5)
     n = 5000
-    for fmt in (N.PIXELS_U16, N.PIXELS_F16):
-        rec = rng.integers(0, 255, (n, E.PEAK_RECORD_BYTES), dtype=np.uint8)
-        v = E.peak_record_view(rec)
+    for fmt in (N.PIXELS_U16, N.PIXELS_F16, N.PIXELS_U32):
+        rec = rng.integers(0, 255, (n, E.peak_record_bytes(fmt)), dtype=np.uint8)
+        v = E.peak_record_view(rec, fmt)
+        assert v.dtype.itemsize == (428 if fmt == N.PIXELS_U32 else 378)
         v["key_h"] = rng.integers(0, 512, n)
         v["key_w"] = np.arange(n)
         for k in ("h0", "w0", "H", "A", "sigma_h", "sigma_w", "theta", "rmse", "r2", "s_n"):
             v[k] = rng.normal(0, 100, n)
         v["r2"][::7] = np.nan
         v["fit"] = rng.normal(0, 1, (n, 5, 5))
-        v["sub"] = rng.integers(0, 0x7c00 if fmt == N.PIXELS_F16 else 65536, (n, 5, 5))
+        v["sub"] = rng.integers(0, {N.PIXELS_F16: 0x7c00, N.PIXELS_U16: 65536, N.PIXELS_U32: 2 ** 31}[fmt], (n, 5, 5))
         counts = rng.multinomial(n, np.ones(40) / 40)
         counts[3] = 0
         offs = np.concatenate([[0], np.cumsum(counts)])
