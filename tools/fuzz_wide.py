@@ -42,12 +42,12 @@ def wide_field(H, W):
     elif kind == 1:
         img = img * int(rng.integers(2, 3000)) + int(rng.integers(0, 1 << 28))
     elif kind == 2:                                         # saturating at the top of the domain
-        img = np.minimum(img * int(rng.integers(20000, 400000)), TOP)
+        img = np.minimum(img * int(rng.integers(20000, 400000)), TOP) if rng.random() < 0.3 else np.minimum(img * int(rng.integers(2000, 40000)), TOP)
     elif kind == 3:                                         # pure noise over a random range
-        img = rng.integers(0, int(rng.integers(70000, TOP)), (H, W))
+        img = rng.integers(0, int(rng.integers(70000, TOP if rng.random() < 0.2 else 1 << 24)), (H, W))
     elif kind == 4:                                         # 16-bit background, a few enormous pixels
         hot = rng.random((H, W)) < 0.002
-        img = np.where(hot, rng.integers(1 << 20, TOP, (H, W)), img)
+        img = np.where(hot, rng.integers(1 << 20, TOP if rng.random() < 0.3 else 1 << 27, (H, W)), img)
     else:                                                   # barely beyond 16 bits
         img = img + 65000
     img = np.clip(img, 0, TOP)
@@ -57,7 +57,7 @@ def wide_field(H, W):
 
 
 # ---- 1. fields through find_peptides_batch ---------------------------------------------------------------------------------
-n_fields = n_peaks = n_assert = 0
+n_fields = n_peaks = n_assert = n_refused = 0
 for shape_i in range(n_shapes):
     H, W = int(rng.integers(24, 150)), int(rng.integers(24, 150))
     nf = int(rng.integers(3, 14))
@@ -74,22 +74,30 @@ for shape_i in range(n_shapes):
     imgs = np.stack([wide_field(H, W) for _ in range(nf)])
     old = pflib.CHUNK_PIXELS
     pflib.CHUNK_PIXELS = int(rng.integers(1, nf + 1)) * H * W          # slices of 1 .. nf fields (the last one padded)
+    kw = dict(median_filter_size=med, correlation_matrix=K, c_std=c_std, r_2_threshold=r2, consolidation_radius=rad)
     try:
-        got = pflib.find_peptides_batch(imgs, median_filter_size=med, correlation_matrix=K, c_std=c_std, r_2_threshold=r2,
-                                        consolidation_radius=rad, errors='return')
-    except NotImplementedError as e:        # (the response of a field sums to 2^53 or more: refused by design - the oracle says so too)
+        got = pflib.find_peptides_batch(imgs, errors='return', **kw)
+    except NotImplementedError:
+        # the response image of some field sums to 2^53 or more, where numpy.mean (pflib.py:250) is no longer the exact integer
+        # mean: refused by design, for the whole stack.  Field by field then: refused exactly where the oracle refuses
+        got, n_ref = [], 0
         for f in range(nf):
             try:
-                O.candidates(imgs[f], med_size=med, K=K, c_std=c_std)
-            except ValueError:
-                break
-        else:
-            raise AssertionError("shape %d: the GPU path refused (%s) what the oracle accepts" % (shape_i, e))
-        print("shape %d refused (field sum beyond 2^53), as the oracle" % shape_i, flush=True)
-        continue
+                got.append(pflib.find_peptides_batch(imgs[f:f + 1], errors='return', **kw)[0])
+            except NotImplementedError:
+                try:
+                    O.candidates(imgs[f], med_size=med, K=K, c_std=c_std)
+                except ValueError:
+                    got.append(None)
+                    n_ref += 1
+                else:
+                    raise AssertionError("shape %d field %d: the GPU path refused what the oracle accepts" % (shape_i, f))
+        n_refused += n_ref
     finally:
         pflib.CHUNK_PIXELS = old
     for f, d in enumerate(got):
+        if d is None:
+            continue
         try:
             rows, fits, keep, key = O.find_peptides(imgs[f], med_size=med, K=K, c_std=c_std, r2_thr=r2, radius=rad, n_threads=16)
         except AssertionError:
@@ -109,7 +117,8 @@ for shape_i in range(n_shapes):
         n_peaks += len(vals)
     n_fields += nf
     print("shape %d: %dx%d x %d fields ok (%.0f s)" % (shape_i, H, W, nf, time.time() - t0), flush=True)
-print("fields: %d checked, %d peaks, %d re-key assertions reproduced" % (n_fields, n_peaks, n_assert), flush=True)
+print("fields: %d checked, %d peaks, %d re-key assertions reproduced, %d fields refused as by the oracle (response sum >= 2^53)"
+      % (n_fields, n_peaks, n_assert, n_refused), flush=True)
 
 # ---- 2. adversarial ROIs ----------------------------------------------------------------------------------------------------
 torch = E._torch()
