@@ -34,6 +34,18 @@ def test_golden(env):
         assert np.array_equal(ph.gaussian_volume_photometry_metric(fits).view(np.uint64), g["gaussian_volume_" + name].view(np.uint64))
 
 
+def test_large_windows_equal_reference(env):
+    """(brim, radius) = (6, 16), (10, 40), (3, 150) against the reference's recorded values (tests/golden/photometry_wide.npz): the
+    any-radius kernel of round 4."""
+    ph, pflib, synth, O = env
+    g = np.load(os.path.join(GOLD, "photometry_wide.npz"))
+    _, img = load_field(str(g["name"]))
+    for brim, radius in g["cases"]:
+        exp = g["mexican_hat_b%d_r%d" % (brim, radius)]
+        got = ph.mexican_hat_photometry_metric(img, g["hw"], brim_size=int(brim), radius=int(radius))
+        assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.array_equal(got[~np.isnan(exp)], exp[~np.isnan(exp)]), (brim, radius)
+
+
 def test_random_spots_and_shapes_vs_oracle(env):
     ph, pflib, synth, O = env
     rng = np.random.default_rng(5)

@@ -29,6 +29,16 @@ def test_tracking_equals_reference(env, case):
     assert np.array_equal(prev, o_prev) and np.array_equal(nxt, o_next) and np.array_equal(kept, o_kept)
 
 
+@pytest.mark.parametrize("case", list(load_cases("tracking_long.npz")), ids=lambda c: c[0])
+def test_long_series_and_large_fields_equal_reference(env, case):
+    """90 / 70 frames and 34 000 spots (tests/golden/tracking_long.npz: the reference's own traces): the frame tables in the
+    workspace instead of LDS, the pairing facts read off the links instead of LDS bitmaps."""
+    torch, N, fl, O = env
+    name, frame_hw, offsets, shape, radius, spot_radius, traces, discarded = case
+    got, nd, prev, nxt, kept = fl.track_fields([frame_hw], [offsets], shape, radius, spot_radius)[0]
+    assert nd == discarded and got.shape == traces.shape and np.array_equal(got, traces)
+
+
 def test_tracking_batch_and_object_surface(env):
     """Many fields per launch (random layouts vs the oracle), and the Experiment.greedy_particle_tracking surface on
     Spot-like objects."""

@@ -219,3 +219,14 @@ def test_photometry_matches_reference():
         assert np.array_equal(O.mexican_hat(img, hw), g["mexican_hat_b6_r9_" + name])
         assert np.array_equal(O.mexican_hat(img, hw, 2, 4), g["mexican_hat_b2_r4_" + name])
         assert np.array_equal(O.gaussian_volume(g["fit7_" + name]).view(np.uint64), g["gaussian_volume_" + name].view(np.uint64))
+
+
+def test_photometry_with_large_windows_matches_reference():
+    """Mexican-hat windows beyond 31 x 31 - (brim, radius) = (6, 16), (10, 40), (3, 150: larger than the image) - as recorded from
+    the reference (tests/golden/photometry_wide.npz, oracle/gen_golden.py --only phot_wide)."""
+    g = np.load(os.path.join(GOLD, "photometry_wide.npz"))
+    _, img = load_field(str(g["name"]))
+    for brim, radius in g["cases"]:
+        exp = g["mexican_hat_b%d_r%d" % (brim, radius)]
+        got = O.mexican_hat(img, g["hw"], int(brim), int(radius))
+        assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.array_equal(got[~np.isnan(exp)], exp[~np.isnan(exp)]), (brim, radius)

@@ -15,8 +15,8 @@ def _build():
     O.build()
 
 
-def load_cases():
-    g = np.load(os.path.join(GOLD, "tracking.npz"))
+def load_cases(file="tracking.npz"):
+    g = np.load(os.path.join(GOLD, file))
     for name in g["names"]:
         name = str(name)
         counts = g[name + "_counts"]
@@ -40,6 +40,17 @@ def test_oracle_tracking_equals_reference(case):
     assert nd == discarded
     assert got.shape == traces.shape and np.array_equal(got, traces)
     assert int((~kept).sum()) == discarded
+
+
+@pytest.mark.parametrize("case", list(load_cases("tracking_long.npz")), ids=lambda c: c[0])
+def test_oracle_tracking_equals_reference_on_long_series_and_large_fields(case):
+    """A 90-frame series (drift, drop-outs, re-appearing spots, the stage returning to its start) and a field of 34 000 spots
+    through the reference itself (oracle/gen_golden.py --only track_long): beyond the 64 frames / 32 768 spots the GPU tracker
+    was limited to until round 4."""
+    name, frame_hw, offsets, shape, radius, spot_radius, traces, discarded = case
+    assert len(frame_hw) > 64 or sum(len(x) for x in frame_hw) > 32768
+    got, nd, prev, nxt, kept = O.greedy_tracking(frame_hw, offsets, shape, radius, spot_radius)
+    assert nd == discarded and got.shape == traces.shape and np.array_equal(got, traces)
 
 
 def test_euclid_is_dnrm2_of_this_scipy():
