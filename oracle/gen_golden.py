@@ -145,6 +145,12 @@ def parameter_cases():
     k11 = -np.ones((11, 11), dtype=np.int64) * 700
     k11[3:8, 3:8] = 3000
     k11[5, 5] = 25000
+    k15 = rng.integers(-900, 400, (15, 15))
+    k15[5:10, 5:10] = pf_default = np.array([[-5935, -5935, -5935, -5935, -5935], [-5935, 8027, 8027, 8027, -5935],
+                                             [-5935, 8027, 30742, 8027, -5935], [-5935, 8027, 8027, 8027, -5935],
+                                             [-5935, -5935, -5935, -5935, -5935]])
+    k13 = rng.integers(-300, 300, (13, 13))
+    k13[4:9, 4:9] = pf_default // 2
     return {
         "p0_med3_k3_r2": dict(seed=61, shape=(112, 112), n_spots=14, kind="std",
                               params=dict(median_filter_size=3, correlation_matrix=k3, c_std=1.5, r_2_threshold=0.5, consolidation_radius=2)),
@@ -154,6 +160,11 @@ def parameter_cases():
                                params=dict(median_filter_size=4, correlation_matrix=k11, c_std=1.0, r_2_threshold=0.3, consolidation_radius=9)),
         "p3_med9_k5_r3": dict(seed=64, shape=(96, 144), n_spots=30, kind="hard",
                               params=dict(median_filter_size=9, c_std=3, r_2_threshold=0.0, consolidation_radius=3)),
+        # the largest windows the GPU path takes (FSQ_MAX_KSIZE = 15; 9 until round 4)
+        "p4_med15_k15_r4": dict(seed=65, shape=(104, 120), n_spots=16, kind="std",
+                                params=dict(median_filter_size=15, correlation_matrix=k15, c_std=2, r_2_threshold=0.6, consolidation_radius=4)),
+        "p5_med11_k13_r5": dict(seed=66, shape=(128, 100), n_spots=30, kind="hard",
+                                params=dict(median_filter_size=11, correlation_matrix=k13, c_std=1.5, r_2_threshold=0.4, consolidation_radius=5)),
     }
 
 

@@ -15,7 +15,7 @@ FIELD_NAMES = ["f0_cfg1_512_200", "f1_cfg2_512_500", "f2_rect_384x640_300", "f3_
 DEGEN_NAMES = ["d0_flat_32", "d1_sat_40", "d2_satpart_48", "d3_dim_48", "d4_noise_40", "d5_noise_lo_36",
                "d6_hotpixel_32", "d7_zero_24"]
 TEXTBOOK_NAMES = ["f5_small_96", "f3_hard_256"]
-PARAM_NAMES = ["p0_med3_k3_r2", "p1_med7_k7_r6", "p2_med4_k11_r9", "p3_med9_k5_r3"]          # non-default find_peptides keywords
+PARAM_NAMES = ["p0_med3_k3_r2", "p1_med7_k7_r6", "p2_med4_k11_r9", "p3_med9_k5_r3", "p4_med15_k15_r4", "p5_med11_k13_r5"]          # non-default find_peptides keywords
 
 
 def golden_params(g):
