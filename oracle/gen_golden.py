@@ -9,7 +9,7 @@ fluorosequencingimageanalysis_amd/synth.py.  The .npz files hold DATA only
 
 Usage (about 4 minutes on 8 cores):
   NPY_DISABLE_CPU_FEATURES="AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL AVX512_SPR" \
-      python oracle/gen_golden.py [--only fields|reg|kat|phot|phot_wide|degen|params|wide|textbook|io|loader|track|track_long|centroid]
+      python oracle/gen_golden.py [--only fields|reg|kat|phot|phot_wide|degen|params|tiny|wide|textbook|io|loader|track|track_long|centroid]
 
 Golden sets: G1 per-ROI fits, G2 candidate lists, G3 full
 find_peptides tables, G4 phase_correlate tuples, G5 known-answer tests.
@@ -165,6 +165,33 @@ def parameter_cases():
                                 params=dict(median_filter_size=15, correlation_matrix=k15, c_std=2, r_2_threshold=0.6, consolidation_radius=4)),
         "p5_med11_k13_r5": dict(seed=66, shape=(128, 100), n_spots=30, kind="hard",
                                 params=dict(median_filter_size=11, correlation_matrix=k13, c_std=1.5, r_2_threshold=0.4, consolidation_radius=5)),
+    }
+
+
+def tiny_cases():
+    """Frames barely larger than - or as small as - one 5 x 5 neighbourhood, some with median windows and correlation matrices
+    LARGER than the frame (scipy's 'reflect' indexing wraps more than once, the zero-padded correlation sees mostly padding)
+    -> tests/golden/tiny_*.npz."""
+    rng = np.random.default_rng(555)
+
+    def spot(shape, c, amp, floor=200, noise=30):
+        yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
+        g = amp * np.exp(-((yy - c[0]) ** 2 + (xx - c[1]) ** 2) / (2 * 1.1 ** 2))
+        return np.clip(np.rint(floor + g + rng.normal(0, noise, shape)), 0, 65535).astype(np.uint16)
+    k7 = rng.integers(-2000, 3000, (7, 7))
+    k7[3, 3] = 30000
+    k9 = -np.ones((9, 9), dtype=np.int64) * 500
+    k9[3:6, 3:6] = 4000
+    return {
+        "t0_5x5": dict(image=spot((5, 5), (2.2, 1.9), 4000)),
+        "t1_5x9_c1": dict(image=spot((5, 9), (2.0, 4.3), 6000), params=dict(c_std=1)),
+        "t2_6x6_med7": dict(image=spot((6, 6), (2.6, 3.1), 5000), params=dict(median_filter_size=7, c_std=1)),
+        "t3_7x12_k7": dict(image=spot((7, 12), (3.3, 6.2), 9000), params=dict(correlation_matrix=k7, c_std=1, r_2_threshold=0.2)),
+        "t4_9x5_k9_med9": dict(image=spot((9, 5), (4.4, 2.1), 7000),
+                               params=dict(median_filter_size=9, correlation_matrix=k9, c_std=0.5, r_2_threshold=0.0, consolidation_radius=2)),
+        "t5_8x8_med15_k15": dict(image=spot((8, 8), (3.7, 4.2), 8000),
+                                 params=dict(median_filter_size=15, correlation_matrix=np.pad(k7, 4, constant_values=-100), c_std=0.5,
+                                             r_2_threshold=0.1, consolidation_radius=3)),
     }
 
 
@@ -690,6 +717,9 @@ def main():
     if a.only in ("", "params"):
         with mp.Pool(a.procs) as pool:
             gen_fields(pool, with_stability=(), fields=parameter_cases(), prefix="params_")
+    if a.only in ("", "tiny"):
+        with mp.Pool(a.procs) as pool:
+            gen_fields(pool, with_stability=(), fields=tiny_cases(), prefix="tiny_")
     if a.only in ("", "wide"):
         with mp.Pool(a.procs) as pool:
             gen_fields(pool, with_stability=(), fields={k: {"image": v} for k, v in wide_images().items()}, prefix="wide_")

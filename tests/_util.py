@@ -28,6 +28,7 @@ def golden_params(g):
     return out
 
 
+TINY_NAMES = ["t0_5x5", "t1_5x9_c1", "t2_6x6_med7", "t3_7x12_k7", "t4_9x5_k9_med9", "t5_8x8_med15_k15"]   # frames of one 5 x 5 neighbourhood or little more
 WIDE_NAMES = ["w0_22bit_128", "w1_28bit_96", "w2_mixed_96", "w3_hard_20bit_112"]       # uint32 frames beyond 16 bits
 
 

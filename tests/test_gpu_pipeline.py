@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from _util import FIELD_NAMES, PARAM_NAMES, bits_equal, golden_params, load_field
+from _util import FIELD_NAMES, PARAM_NAMES, TINY_NAMES, bits_equal, golden_params, load_field
 
 pytestmark = pytest.mark.gpu
 
@@ -87,12 +87,14 @@ def test_nondefault_parameters(env):
         assert bits_equal(got, exp).all()
 
 
-@pytest.mark.parametrize("name", PARAM_NAMES)
+@pytest.mark.parametrize("name", ["params_" + n for n in PARAM_NAMES] + ["tiny_" + n for n in TINY_NAMES])
 def test_nondefault_keywords_equal_reference(env, name):
     """find_peptides with non-default median windows / correlation matrices / c_std / r_2 threshold / consolidation radius
-    against the reference's own recorded tables (tests/golden/params_*.npz, oracle/gen_golden.py --only params)."""
+    against the reference's own recorded tables (tests/golden/params_*.npz, oracle/gen_golden.py --only params), and on frames
+    of one 5 x 5 neighbourhood or little more, smaller than their windows (tiny_*.npz, --only tiny)."""
     torch, pflib, engine, O = env
-    g, img = load_field(name, prefix="params_")
+    prefix, name = name.split("_", 1)
+    g, img = load_field(name, prefix=prefix + "_")
     prm = golden_params(g)
     det = {k: prm[k] for k in ("median_filter_size", "correlation_matrix", "c_std") if k in prm}
     assert pflib._psf_candidates(img, **det) == [tuple(int(v) for v in hw) for hw in g["candidates"]]

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import oracle as O
-from _util import (DEGEN_NAMES, FIELD_NAMES, GOLD, PARAM_NAMES, TEXTBOOK_NAMES, WIDE_NAMES, bits_equal, golden_params, load_field,
+from _util import (DEGEN_NAMES, FIELD_NAMES, GOLD, PARAM_NAMES, TEXTBOOK_NAMES, TINY_NAMES, WIDE_NAMES, bits_equal, golden_params, load_field,
                    rois_of)
 
 
@@ -98,6 +98,15 @@ def test_nondefault_keywords_match_reference(name):
     prm = golden_params(g)
     assert prm and int(g["table_error"]) == 0 and len(g["table_keys"]) > 5
     _check_against_golden(g, img, mode=0, prm=prm)
+
+
+@pytest.mark.parametrize("name", TINY_NAMES)
+def test_tiny_frames_match_reference(name):
+    """5 x 5 ... 9 x 5 frames, some smaller than their median window / correlation matrix (scipy's 'reflect' index wraps more than
+    once; the correlation sees mostly zero padding), through the unmodified reference (oracle/gen_golden.py --only tiny)."""
+    g, img = load_field(name, prefix="tiny_")
+    assert min(img.shape) <= 9 and len(g["candidates"]) >= 1 and len(g["table_keys"]) >= 1
+    _check_against_golden(g, img, mode=0, prm=golden_params(g))
 
 
 @pytest.mark.parametrize("name", WIDE_NAMES)
