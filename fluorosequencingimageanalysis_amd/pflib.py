@@ -266,6 +266,29 @@ def _wide_pass(eng, imgs, prm, r_2_threshold, radius, mode):
     return _records_to_dicts(rows, fit, sub, offs.cpu().numpy(), failed)
 
 
+#: stacks of at most this many pixels - one image, a few small ones - are worked by ONE library call on the calling thread
+#: (_small_pass) instead of the _BatchRunner's stager / lanes / builder threads, which only pay off over several chunks
+SMALL_PASS_PIXELS = 8 * 512 * 512
+
+
+def _small_pass(imgs, fmt, prm, r_2_threshold, radius, mode):
+    """find_peptides of a small stack: upload, fsq_find_peptides (the whole path in one call, engine.PathRunner), records back,
+    dicts - on the calling thread, with a cached runner of the stack's shape (a single image used to set up four
+    pinned buffers, three lanes and their threads)."""
+    n, H, W = imgs.shape
+    wide = fmt == N.PIXELS_U32
+    def build():
+        r = _engine.PathRunner(n, H, W, record_bytes=_engine.peak_record_bytes(fmt))
+        r.lock = threading.Lock()           # (its buffers serve one call at a time; other shapes' runners are not held up)
+        return r
+    runner = _cached(("small", _device_key(), n, H, W, wide), build)
+    with runner.lock:
+        rec, offs, nk, _ = runner.run(_engine.to_device_pixels(imgs, fmt), prm, r_2_threshold, radius, mode, PY2_ROUND)
+        rec, offs, nk = rec.cpu().numpy(), offs.cpu().numpy(), nk.cpu().numpy()
+    failed = set(int(f) for f in np.nonzero(nk[:n] < 0)[0])
+    return _records_to_dicts(_engine.peak_record_view(rec, fmt), None, None, offs, failed, fmt)
+
+
 #: find_peptides_batch streams a stack through the GPU in chunks of about this many pixels (engine.StreamPipeline)
 CHUNK_PIXELS = 128 * 512 * 512
 #: (kept for callers that tuned it: the largest stack that used to be worked as ONE pass)
@@ -641,6 +664,11 @@ def find_peptides_batch(images, median_filter_size=5, correlation_matrix=default
         d_img = _engine.to_device_u16(imgs)
         engine.run(d_img, prm, r_2_threshold, consolidation_radius, mode, PY2_ROUND)
         out = _engine_dicts(engine, d_img, fmt)
+    elif (n * H * W <= min(SMALL_PASS_PIXELS, CHUNK_PIXELS) and mode != N.MODE_TEXTBOOK_F32
+          and "FSQ_BATCH_LANES" not in os.environ):            # (one chunk, and a small one)
+        out = _small_pass(imgs, fmt, prm, r_2_threshold, consolidation_radius, mode)
+        if on_chunk is not None:
+            on_chunk(0, out)
     else:
         n_chunks = max(1, -(-(n * H * W) // CHUNK_PIXELS))
         per = -(-n // n_chunks)

@@ -82,9 +82,11 @@ def test_chunked_batch_equals_one_pass(env, monkeypatch):
     same dicts as one pass."""
     cli, pflib, synth, O = env
     imgs = np.stack([synth.make_field(600 + i, (96, 96), 8 + i) for i in range(11)])
-    one = pflib.find_peptides_batch(imgs)
+    one = pflib.find_peptides_batch(imgs)                   # (a small stack: one library call on this thread, pflib._small_pass)
+    assert any(k[0] == "small" and k[2:5] == (11, 96, 96) for k in pflib._CACHE)
     monkeypatch.setattr(pflib, "CHUNK_PIXELS", 3 * 96 * 96)
-    many = pflib.find_peptides_batch(imgs)
+    many = pflib.find_peptides_batch(imgs)                  # (chunks of 3 fields through the runner's lanes)
+    assert any(k[0] == "batch" and k[2:5] == (3, 96, 96) for k in pflib._CACHE)
     assert len(one) == len(many) == 11
     for a, b in zip(one, many):
         assert list(a.keys()) == list(b.keys())
