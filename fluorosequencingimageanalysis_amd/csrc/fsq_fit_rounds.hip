@@ -1984,7 +1984,11 @@ extern "C" int fsq_fitq_create(FsqFitQueue** out, void* d_workspace, int64_t wor
                                int64_t queue_cap, int mode, void* stream)
 {
     if (!out || pool_slots <= 0 || queue_cap <= 0) return FSQ_EINVAL;
-    if (mode != FSQ_MODE_REF && mode != FSQ_MODE_TEXTBOOK && mode != FSQ_MODE_TEXTBOOK_F32) return FSQ_EINVAL;       // (16-bit pixel formats only)
+    // mode | FSQ_PIXELS_U32_FLAG: a queue for batches of uint32 pixels (and for nothing else: the compact ROI copies of all
+    // batches in flight share one word size); the two 16-bit formats may be mixed in one queue
+    const int m = mode & ~FSQ_PIXELS_U32_FLAG;
+    if (m != FSQ_MODE_REF && m != FSQ_MODE_TEXTBOOK && m != FSQ_MODE_TEXTBOOK_F32) return FSQ_EINVAL;
+    if ((mode & FSQ_PIXELS_U32_FLAG) && m == FSQ_MODE_TEXTBOOK_F32) return FSQ_ENOTIMPL;
     FsqFitQueue* q = new (std::nothrow) FsqFitQueue();
     if (!q) return FSQ_ENOMEM;
     int rc = q->init(d_workspace, workspace_bytes, (size_t)pool_slots, (size_t)queue_cap, mode, (hipStream_t)stream, false);

@@ -198,16 +198,32 @@ def find_peptides_sharded(images, partition="lpt", dst=0, n_fields=None, output=
     else:
         parts = _partition(n, world, partition)
     mine = parts[rank]
+    # one record format for the whole job: a share with a pixel value beyond 16 bits makes every rank work uint32 words
+    # (428-byte records), so that the gathered table has one row width
+    share, wide_local = None, 0
     try:
         for i in [i for i in held if i not in mine]:
             del held[i]
-        if output == "local":
-            local = dict(zip(mine, pflib.find_peptides_batch(load(mine), errors='return', **fp))) if mine else {}
-        elif mine:
-            rec, counts, fmt = pflib.find_peptides_records(load(mine), device=True, **fp)
-        else:
-            rec, counts = torch.zeros((0, E.PEAK_RECORD_BYTES), dtype=torch.uint8, device=dev), np.zeros(0, np.int32)
+        if mine:
+            share = load(mine)
+            wide_local = int(share.dtype != np.float16 and share.size > 0 and float(share.max()) > 65535)
         held.clear()
+    except Exception as e:      # noqa: BLE001
+        err = e
+    _all_ranks_ok(err)
+    t_wide = torch.tensor([wide_local], dtype=torch.int32)
+    t_wide = t_wide if gloo else t_wide.to(dev)
+    dist.all_reduce(t_wide, op=dist.ReduceOp.MAX)
+    wide = bool(int(t_wide.item()))
+    try:
+        if output == "local":
+            local = dict(zip(mine, pflib.find_peptides_batch(share, errors='return', **fp))) if mine else {}
+        elif mine:
+            rec, counts, fmt = pflib.find_peptides_records(share, device=True, wide=wide, **fp)
+        else:
+            rec = torch.zeros((0, E.PEAK_RECORD_BYTES_U32 if wide else E.PEAK_RECORD_BYTES), dtype=torch.uint8, device=dev)
+            counts = np.zeros(0, np.int32)
+        share = None
     except Exception as e:      # noqa: BLE001
         err = e
     _all_ranks_ok(err)

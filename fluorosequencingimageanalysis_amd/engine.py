@@ -57,9 +57,10 @@ def as_u16_fields(image):
     return np.ascontiguousarray(a.astype(np.uint16))
 
 
-def as_pixel_fields(image):
-    """-> (16-bit words to upload, pixel format).  Integer images are validated like as_u16_fields; a float16 image
-    (BASELINE.json configs[4]: pixel values pre-scaled into binary16) is uploaded as it is and truncated toward zero
+def as_pixel_fields(image, wide=False):
+    """-> (pixel words to upload, pixel format).  Integer images (and floats, truncated toward zero) whose values fit 16 bits
+    become uint16 words; with a value beyond 65 535 - or with wide=True - uint32 words (PIXELS_U32, values below 2^31); a
+    float16 image (BASELINE.json configs[4]: pixel values pre-scaled into binary16) is uploaded as it is and truncated toward zero
     by the kernels' loads, which is what the reference's image.astype(np.int64) (pflib.py:241, 443) does with it."""
     a = np.asarray(image)
     if a.dtype == np.float16:
@@ -70,9 +71,12 @@ def as_pixel_fields(image):
         if a.size and not np.isfinite(a).all():
             raise NotImplementedError("non-finite pixel values are not supported by the GPU path")
         a = a.astype(np.int64)                      # truncation toward zero, as the reference
+    if wide and a.dtype.kind in "iub" and a.dtype != np.float16:      # (the caller wants uint32 words whatever the values are)
+        if a.size and (int(a.min()) < 0 or int(a.max()) >= 2 ** 31):
+            raise NotImplementedError("pixel values outside [0, 2^31) are not supported by the GPU path")
+        return np.ascontiguousarray(a.astype(np.uint32)), N.PIXELS_U32
     if a.dtype.kind in "iu" and a.dtype.itemsize > 2 and a.size and int(a.max()) > 65535:
-        # beyond 16 bits (round 4): uint32 words, PIXELS_U32 - detection, fits and consolidation as for 16-bit pixels
-        # (stand-alone Engine passes; the streaming fit queue and the 378-byte peak records stay 16-bit)
+        # beyond 16 bits (round 4): uint32 words, PIXELS_U32 - detection, fits, consolidation and records as for 16-bit pixels
         if int(a.min()) < 0 or int(a.max()) >= 2 ** 31:
             raise NotImplementedError("pixel values outside [0, 2^31) are not supported by the GPU path")
         return np.ascontiguousarray(a.astype(np.uint32)), N.PIXELS_U32
@@ -327,7 +331,8 @@ class Engine:
     def peak_records(self, d_img):
         """Everything pflib's 12-tuple holds, per kept peak, as one device byte table uint8[k, PEAK_RECORD_BYTES]:
         the FsqRow (128 B), fit_img float64[25] (200 B), sub_img uint16[25] (50 B) - the unit of the multi-GPU
-        gather.  -> (records, per-field offsets int32[n_fields + 1])."""
+        gather (d_img int32-typed, PIXELS_U32: uint32[25], 100 B, records of PEAK_RECORD_BYTES_U32).
+        -> (records, per-field offsets int32[n_fields + 1])."""
         torch = self.torch
         table, offs = self.kept_table()
         k = table.shape[0]
@@ -337,8 +342,8 @@ class Engine:
         hh = (ints[:, 0].long()[:, None, None] + d[None, :, None]).expand(k, 5, 5)
         ww = (ints[:, 1].long()[:, None, None] + d[None, None, :]).expand(k, 5, 5)
         ff = ints[:, 2].long()[:, None, None].expand(k, 5, 5)
-        sub = d_img[ff, hh, ww].contiguous()                              # int16-typed uint16 pixels (pflib.py:443)
-        rec = torch.cat([table, fit.view(torch.uint8).reshape(k, 200), sub.view(torch.uint8).reshape(k, 50)], dim=1)
+        sub = d_img[ff, hh, ww].contiguous()                              # int16- / int32-typed pixel words (pflib.py:443)
+        rec = torch.cat([table, fit.view(torch.uint8).reshape(k, 200), sub.view(torch.uint8).reshape(k, 25 * sub.element_size())], dim=1)
         return rec, offs
 
     # ---- host-side extraction --------------------------------------------------------------
@@ -491,9 +496,13 @@ class StreamPipeline:
     1082-1099)."""
 
     def __init__(self, n_fields, H, W, depth=16, cand_per_batch=None, inject_below=None, device=None,
-                 mode=N.MODE_REF, cand_per_field=None):
+                 mode=N.MODE_REF, cand_per_field=None, wide=False):
+        """wide: a pipeline for PIXELS_U32 frames (its fit queue is created for 32-bit pixels and takes nothing else)."""
         torch = _torch()
         self.torch = torch
+        self.wide = bool(wide)
+        if self.wide and mode == N.MODE_TEXTBOOK_F32:
+            raise NotImplementedError("the single-precision solver takes 16-bit pixels only")
         self.dev = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
         self.n_fields, self.H, self.W = int(n_fields), int(H), int(W)
         self.depth = max(2, min(int(depth), N.MAX_TICKETS))
@@ -532,7 +541,7 @@ class StreamPipeline:
         with _ALLOC_LOCK, torch.cuda.device(self.dev), torch.cuda.stream(torch.cuda.default_stream(self.dev)):
             self.queue = FitQueue(pool_slots=min((self.depth + 2) * per, (1 << 27) - 1),
                                   queue_cap=64 if self.mode == N.MODE_TEXTBOOK_F32 else 2 * per + per // 2,
-                                  mode=self.mode, device=self.dev, stream=self.fit_stream)
+                                  mode=self.mode | (N.PIXELS_U32_FLAG if self.wide else 0), device=self.dev, stream=self.fit_stream)
         # (the injection threshold stays a quarter of the engines' candidate capacity, as tuned on bench.py's batches)
         self.inject_below = int(self._inject_below_arg if self._inject_below_arg is not None else min(per, self.engines[0].cap) // 4
                                 if self.cand_per_batch_fixed else self.engines[0].cap // 4)

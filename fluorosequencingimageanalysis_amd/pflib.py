@@ -353,8 +353,7 @@ class _BatchRunner:
     12-tuples overlap the fitting instead of following it (1 024 fields: 0.60 s -> 0.45 s)."""
 
     def __init__(self, per, H, W, mode=N.MODE_REF, wide=False):
-        """wide: the runner of PIXELS_U32 stacks (uint32 staging buffers, 428-byte records); such stacks always take the lanes
-        (the fit queue of the continuous-batching pipeline carries 16-bit pixels)."""
+        """wide: the runner of PIXELS_U32 stacks (uint32 staging buffers, 428-byte records, a fit queue for 32-bit pixels)."""
         torch = _engine._torch()
         self.torch = torch
         self.per, self.H, self.W = int(per), int(H), int(W)
@@ -394,8 +393,8 @@ class _BatchRunner:
         import sys
         torch, per = self.torch, self.per
         n_lanes = 0 if (raw or self.mode == N.MODE_TEXTBOOK_F32) else int(os.environ.get("FSQ_BATCH_LANES", DICT_LANES))
-        if self.wide != (fmt == N.PIXELS_U32) or (self.wide and n_lanes <= 0):
-            raise NotImplementedError("pixel values beyond 16 bits go through the dict-building lanes only")
+        if self.wide != (fmt == N.PIXELS_U32):
+            raise ValueError("this runner was built for %s pixels" % ("32-bit" if self.wide else "16-bit"))
         n = len(words)
         if n_lanes > 0:
             # lanes take chunks of any size up to `per`: the first ones are small so that the first records - and with them the
@@ -528,7 +527,7 @@ class _BatchRunner:
                 else:       # through a pinned buffer that is re-used (this thread works one chunk at a time): no fresh pages
                     k = rec.shape[0]
                     if self.rec_pin is None or self.rec_pin.shape[0] < k:
-                        self.rec_pin = torch.empty((k + k // 4 + 1024, _engine.PEAK_RECORD_BYTES), dtype=torch.uint8).pin_memory()
+                        self.rec_pin = torch.empty((k + k // 4 + 1024, self.rec_bytes), dtype=torch.uint8).pin_memory()
                     self.rec_pin[:k].copy_(rec, non_blocking=True)
                 meta = torch.cat([nk.to(torch.int32), offs.to(torch.int32)]).cpu().numpy()    # (synchronises this thread's stream)
                 nk, offs = meta[:len(nk)], meta[len(nk):]
@@ -536,7 +535,7 @@ class _BatchRunner:
                 out[c] = (rec_host, np.where(nk < 0, nk, np.diff(offs)).astype(np.int32))
                 return
             failed = set(int(f) for f in np.nonzero(nk < 0)[0])
-            dicts = _records_to_dicts(_engine.peak_record_view(self.rec_pin[:k].numpy()), None, None, offs, failed, fmt)
+            dicts = _records_to_dicts(_engine.peak_record_view(self.rec_pin[:k].numpy(), fmt), None, None, offs, failed, fmt)
             if n_lanes > 0:
                 out[first[c]:first[c + 1]] = dicts
             else:
@@ -580,7 +579,7 @@ class _BatchRunner:
                 self.land_rec = [None] * (n_lanes + 2)      # pinned landing buffers of the chunks' records / counts
                 self.land_meta = [None] * (n_lanes + 2)
             if n_lanes == 0 and self.pipe is None:
-                self.pipe = _engine.StreamPipeline(self.per, self.H, self.W, depth=12, device=self.dev, mode=self.mode)
+                self.pipe = _engine.StreamPipeline(self.per, self.H, self.W, depth=12, device=self.dev, mode=self.mode, wide=self.wide)
             stager = threading.Thread(target=stage, daemon=True)
             # (the pipeline thread needs the interpreter for a few calls per chunk; while the worker builds dicts it would
             # wait a whole switch interval - 5 ms by default - for each of them)
@@ -611,8 +610,8 @@ class _BatchRunner:
                 with torch.cuda.device(self.dev):
                     for r in recs:          # (allocated on the pipeline's side stream, read by the concatenation on this thread's)
                         r.record_stream(torch.cuda.current_stream(self.dev))
-                    return (torch.cat(recs) if recs else torch.zeros((0, _engine.PEAK_RECORD_BYTES), dtype=torch.uint8, device=self.dev)), counts
-            return np.concatenate(recs) if recs else np.zeros((0, _engine.PEAK_RECORD_BYTES), np.uint8), counts
+                    return (torch.cat(recs) if recs else torch.zeros((0, self.rec_bytes), dtype=torch.uint8, device=self.dev)), counts
+            return np.concatenate(recs) if recs else np.zeros((0, self.rec_bytes), np.uint8), counts
         return out[:n]
 
 
@@ -682,33 +681,35 @@ def find_peptides_batch(images, median_filter_size=5, correlation_matrix=default
 
 
 def find_peptides_records(images, median_filter_size=5, correlation_matrix=default_correlation_matrix, c_std=2,
-                          r_2_threshold=0.7, consolidation_radius=4, solver='reference', device=False, **unused):
+                          r_2_threshold=0.7, consolidation_radius=4, solver='reference', device=False, wide=None, **unused):
     """find_peptides over a stack, results as the byte tables the multi-GPU gather ships instead of dicts:
-    -> (records uint8[k, engine.PEAK_RECORD_BYTES] of all fields in order, int32[n] peaks per field (-1: the re-key
+    -> (records uint8[k, engine.peak_record_bytes(pixel format)] of all fields in order, int32[n] peaks per field (-1: the re-key
     assertion of pflib.py:518 fired for that field), pixel format).  records_to_dicts turns them into find_peptides' dicts.
-    device=True: the records are returned as a torch uint8 tensor in HBM (never copied to the host)."""
+    device=True: the records are returned as a torch uint8 tensor in HBM (never copied to the host).
+    wide=True: integer pixels are worked as uint32 (428-byte records) even when every value fits 16 bits - for callers whose
+    parts must agree on one record format (the ranks of find_peptides_sharded)."""
     mode = _solver_mode(solver)
     if consolidation_radius < 2:
         raise ValueError("consolidation_radius must be at least 2")
     if unused.get("fit_type", "gauss") != 'gauss':
         raise NotImplementedError("fit_type='monte_carlo' draws from an unseeded RNG in the reference "
                                   "(pflib.py:117-177) and is not reproduced")
-    imgs, fmt = _engine.as_pixel_fields(images)
-    if fmt == N.PIXELS_U32:
-        raise NotImplementedError("peak records carry 16-bit sub_img words: pixel values beyond 65535 go through "
-                                  "find_peptides / find_peptides_batch")
-    prm = _engine.detect_params(median_filter_size, correlation_matrix, c_std, fmt)
+    imgs, fmt = _engine.as_pixel_fields(images, wide=bool(wide))
+    is_wide = fmt == N.PIXELS_U32
+    if is_wide and mode == N.MODE_TEXTBOOK_F32:
+        raise NotImplementedError("solver='textbook_f32' takes 16-bit pixels only")
+    prm = _engine.detect_params(median_filter_size, correlation_matrix, c_std, fmt, _pixel_max(imgs, fmt))
     if imgs.ndim != 3:
         raise ValueError("images must have shape (n, H, W)")
     n, H, W = imgs.shape
     if n == 0 or H < 5 or W < 5:
         if device:
             torch = _engine._torch()
-            return torch.zeros((0, _engine.PEAK_RECORD_BYTES), dtype=torch.uint8, device="cuda"), np.zeros(n, np.int32), fmt
-        return np.zeros((0, _engine.PEAK_RECORD_BYTES), np.uint8), np.zeros(n, np.int32), fmt
+            return torch.zeros((0, _engine.peak_record_bytes(fmt)), dtype=torch.uint8, device="cuda"), np.zeros(n, np.int32), fmt
+        return np.zeros((0, _engine.peak_record_bytes(fmt)), np.uint8), np.zeros(n, np.int32), fmt
     n_chunks = max(1, -(-(n * H * W) // CHUNK_PIXELS))
     per = -(-n // n_chunks)
-    rec, counts = _run_cached_runner(("batch", _device_key(), per, H, W, mode, False), lambda: _BatchRunner(per, H, W, mode),
+    rec, counts = _run_cached_runner(("batch", _device_key(), per, H, W, mode, is_wide), lambda: _BatchRunner(per, H, W, mode, is_wide),
                                      imgs, fmt, prm, r_2_threshold, consolidation_radius, raw=True, device=bool(device))
     return rec, counts, fmt
 

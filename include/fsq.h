@@ -72,9 +72,10 @@ typedef struct FsqRow {
 #define FSQ_PIXELS_F16 1
 #define FSQ_PIXELS_U32 2   /* round 4: uint32 pixels (values < 2^31) for images beyond 16 bits - the reference computes on int64 whatever it
                             * is handed.  Taken by fsq_detect, fsq_fit_candidates (| FSQ_PIXELS_U32_FLAG), fsq_find_peptides (records of
-                            * FSQ_PEAK_RECORD_BYTES_U32 bytes) and fsq_fit_images / fsq_consolidate / fsq_kept_rows (format-independent);
-                            * the fit queue (fsq_fitq_*), the single-precision mode and the photometry / tracking entry points stay 16-bit
-                            * (FSQ_ENOTIMPL / uint16 arguments). */
+                            * FSQ_PEAK_RECORD_BYTES_U32 bytes), a fit queue created for them (fsq_fitq_create with mode |
+                            * FSQ_PIXELS_U32_FLAG: such a queue takes uint32 batches only, any other queue none) and fsq_fit_images /
+                            * fsq_consolidate / fsq_kept_rows (format-independent); the single-precision mode and the photometry /
+                            * tracking entry points stay 16-bit (FSQ_ENOTIMPL / uint16 arguments). */
 
 #define FSQ_MAX_KSIZE 15                           /* largest correlation matrix / median window side (round 4: was 9) */
 typedef struct FsqDetectParams {

@@ -28,6 +28,13 @@ def _fields():
     return np.stack([synth.make_field(300 + i, (128, 128), (5, 60, 10, 40, 25, 8, 50, 30, 15, 35)[i]) for i in range(10)])
 
 
+def _fields_wide():
+    """The same fields as uint32 with ONE of them scaled beyond 16 bits: whichever rank gets it, both must ship 428-byte records."""
+    a = _fields().astype(np.uint32)
+    a[3] *= 100
+    return a
+
+
 def _worker(rank, world, port, q, partition):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
@@ -37,6 +44,11 @@ def _worker(rank, world, port, q, partition):
     from fluorosequencingimageanalysis_amd import distributed as D
     torch.cuda.set_device(0)
     D.init_from_env(backend="gloo")
+    if partition == "records_wide":
+        q.put((rank, D.find_peptides_sharded(_fields_wide(), partition="lpt", output="records", c_std=2)))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if partition in ("records", "local"):      # the forms that scale: byte tables on rank 0 / dicts where the fields were fitted
         from fluorosequencingimageanalysis_amd import pflib
         built = []
@@ -103,10 +115,10 @@ def test_sharded_equals_single_rank(partition):
     _same_dicts(got, single)
 
 
-def _same_records(a, b):
+def _same_records(a, b, fmt=0):
     """Peak records equal byte for byte, except FsqRow.field - the field's number within the chunk of the rank that fitted it."""
     from fluorosequencingimageanalysis_amd import engine as E
-    va, vb = E.peak_record_view(a), E.peak_record_view(b)
+    va, vb = E.peak_record_view(a, fmt), E.peak_record_view(b, fmt)
     assert len(va) == len(vb)
     for name in E.RECORD_DTYPE.names:
         if name != "field":
@@ -142,6 +154,23 @@ def test_sharded_records_output_gathers_bytes_only():
     assert rec.shape == rec1.shape
     _same_records(rec, rec1)
     _same_dicts(pflib.records_to_dicts(rec, counts, fmt), pflib.find_peptides_batch(_fields(), c_std=2))
+
+
+def test_sharded_records_of_wide_pixels_agree_on_one_format():
+    """One field of the stack has pixel values beyond 16 bits: the ranks agree (an all-reduce) to work uint32 words, and rank 0
+    receives the 428-byte records of all fields - equal to find_peptides_records on one GPU."""
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from fluorosequencingimageanalysis_amd import _native as N, engine as E, pflib
+    rec1, counts1, fmt1 = pflib.find_peptides_records(_fields_wide(), c_std=2)
+    assert fmt1 == N.PIXELS_U32 and rec1.shape[1] == E.PEAK_RECORD_BYTES_U32
+    got = _run_two("records_wide")
+    assert got[1] is None
+    rec, counts, fmt = got[0]
+    assert fmt == fmt1 and np.array_equal(counts, counts1) and rec.shape == rec1.shape
+    _same_records(rec, rec1, fmt)
+    d = pflib.records_to_dicts(rec, counts, fmt)
+    assert int(max(v[7].max() for v in d[3].values())) > 65535 and all(len(x) > 0 for x in d)
 
 
 def test_sharded_local_output_builds_dicts_where_the_fields_were_fitted():

@@ -133,6 +133,34 @@ def test_whole_path_in_one_call_and_caller_owned_engine(env):
         E.PathRunner(6, 96, 112).run(E.to_device_pixels(imgs, N.PIXELS_U32), prm)
 
 
+def test_record_tables_through_the_fit_queue(env):
+    """find_peptides_records of wide frames (the continuous-batching pipeline with a fit queue for 32-bit pixels, several chunks,
+    428-byte records) == find_peptides_batch's dicts; wide=True forces the 32-bit route on a 16-bit stack with the same results."""
+    torch, N, E, pflib, synth, O = env
+    imgs = _wide_stack(synth, range(500, 514), (120, 136), 30)
+    ref = pflib.find_peptides_batch(imgs, errors='return')
+    old = pflib.CHUNK_PIXELS
+    pflib.CHUNK_PIXELS = 4 * 120 * 136                  # chunks of 4 fields, the last one padded
+    try:
+        rec, counts, fmt = pflib.find_peptides_records(imgs)
+        rec_d, counts_d, _ = pflib.find_peptides_records(imgs, device=True)
+    finally:
+        pflib.CHUNK_PIXELS = old
+    assert fmt == N.PIXELS_U32 and rec.shape[1] == E.PEAK_RECORD_BYTES_U32 and rec.shape[0] == int(np.maximum(counts, 0).sum()) > 100
+    assert np.array_equal(rec_d.cpu().numpy(), rec) and np.array_equal(counts_d, counts)
+    got = pflib.records_to_dicts(rec, counts, fmt)
+    for a, b in zip(ref, got):
+        assert not isinstance(a, Exception) and list(a) == list(b)
+        for k in a:
+            assert all(np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True) for x, y in zip(a[k], b[k]))
+    small = synth.make_fields(range(3), (96, 96), 12)
+    r16, c16, f16 = pflib.find_peptides_records(small)
+    r32, c32, f32 = pflib.find_peptides_records(small, wide=True)
+    assert f16 == N.PIXELS_U16 and f32 == N.PIXELS_U32 and np.array_equal(c16, c32)
+    assert np.array_equal(r16[:, :328], r32[:, :328])                                    # rows and fit images, byte for byte
+    assert np.array_equal(r16[:, 328:].view(np.uint16).astype(np.uint32), r32[:, 328:].view(np.uint32))
+
+
 def test_every_fit_equals_oracle(env):
     """All candidates' solves of wide frames (kept or not) vs the oracle: parameters, status, iteration and evaluation
     counts, and the metrics of the row."""
@@ -205,14 +233,19 @@ def test_entry_points_that_stay_16_bit_say_so(env):
     assert L.fsq_fit_candidates(*args, N.MODE_TEXTBOOK_F32 | N.PIXELS_U32_FLAG, *tail) == N.FSQ_ENOTIMPL
     assert L.fsq_fit_candidates(*args, N.MODE_REF | N.PIXELS_U32_FLAG | N.PIXELS_F16_FLAG, *tail) == N.FSQ_ENOTIMPL
     assert L.fsq_fit_candidates(*args, N.MODE_REF | N.PIXELS_U32_FLAG | N.ENGINE_QUAD, *tail) == N.FSQ_ENOTIMPL
-    q = E.FitQueue(1 << 12, 1 << 12)
+    q = E.FitQueue(1 << 12, 1 << 12)                    # a queue of 16-bit pixels refuses 32-bit batches, and the other way round
     with pytest.raises(NotImplementedError):
         q.submit(d_img, 1, 64, 64, eng.cand, total, eng.rows, N.PIXELS_U32)
+    q32 = E.FitQueue(1 << 12, 1 << 12, mode=N.MODE_REF | N.PIXELS_U32_FLAG)
+    with pytest.raises(NotImplementedError):
+        q32.submit(E.to_device_u16(img.astype(np.uint16)), 1, 64, 64, eng.cand, total, eng.rows, N.PIXELS_U16)
+    with pytest.raises(NotImplementedError):
+        E.FitQueue(1 << 12, 1 << 12, mode=N.MODE_TEXTBOOK_F32 | N.PIXELS_U32_FLAG)
     prm.pixel_bits = 40
     assert L.fsq_detect(d_img.data_ptr(), 1, 64, 64, ctypes.byref(prm), eng.cand.data_ptr(), eng.cap, eng.counts.data_ptr(),
                         eng.offsets.data_ptr(), eng.thr.data_ptr(), eng.ws.data_ptr(), eng.ws.numel(), None) == N.FSQ_EINVAL
     with pytest.raises(NotImplementedError):
-        pflib.find_peptides_records(img)
+        pflib.find_peptides_records(img, solver='textbook_f32')
     with pytest.raises(NotImplementedError):
         pflib.find_peptides_batch(img, solver='textbook_f32')
     # a correlation matrix whose window sum could leave int64 with 31-bit pixels is refused, not wrapped
