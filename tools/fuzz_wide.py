@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Fuzz of the FSQ_PIXELS_U32 path on the GPU against the oracle (TEST TOOL; results quoted in DESIGN.md):
   1. random wide fields (synthetic fields scaled into 17..31 bits, offsets, noise, saturation at 2^31 - 1) with random detection /
-     consolidation parameters through pflib.find_peptides_batch -> every field's dict == the oracle's find_peptides;
+     consolidation parameters through pflib.find_peptides_batch -> every field's dict == the oracle's find_peptides; the same
+     stack through pflib.find_peptides_records (fit queue for 32-bit pixels, 428-byte records) -> the same dicts;
   2. adversarial stand-alone 5x5 ROIs with 32-bit values (flat, hot pixels, ramps, full-range noise, saturated peaks) laid out as
      a strip image and fitted through fsq_fit_candidates | FSQ_PIXELS_U32_FLAG in both fp64 modes -> parameters, status,
      iteration / evaluation counts and the metrics of every row == the oracle's.
@@ -77,6 +78,16 @@ for shape_i in range(n_shapes):
     kw = dict(median_filter_size=med, correlation_matrix=K, c_std=c_std, r_2_threshold=r2, consolidation_radius=rad)
     try:
         got = pflib.find_peptides_batch(imgs, errors='return', **kw)
+        # the same stack as record tables (the continuous-batching pipeline, a fit queue for 32-bit pixels) must give the same dicts
+        rec, counts, fmt = pflib.find_peptides_records(imgs, **{k: v for k, v in kw.items()})
+        again = pflib.records_to_dicts(rec, counts, fmt)
+        assert fmt == N.PIXELS_U32 and len(again) == len(got)
+        for a, b in zip(got, again):
+            assert isinstance(a, Exception) == isinstance(b, Exception)
+            if not isinstance(a, Exception):
+                assert list(a) == list(b), shape_i
+                for k in a:
+                    assert all(np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True) for x, y in zip(a[k], b[k])), shape_i
     except NotImplementedError:
         # the response image of some field sums to 2^53 or more, where numpy.mean (pflib.py:250) is no longer the exact integer
         # mean: refused by design, for the whole stack.  Field by field then: refused exactly where the oracle refuses
