@@ -26,11 +26,12 @@ __device__ __forceinline__ long long wave_sum_ll(long long v)
     return v;
 }
 
-// smallest value x such that #{brim <= x} >= rank + 1   (rank is 0-based)
+// smallest value x such that #{brim <= x} >= rank + 1   (rank is 0-based); BITS = 16 for uint16 pixels, 31 for uint32 (< 2^31)
+template <int BITS>
 __device__ __forceinline__ unsigned kth_smallest(const unsigned (&v)[PER_LANE], int rank)
 {
-    unsigned lo = 0, hi = 65535;
-    for (int it = 0; it < 16; it++) {
+    unsigned lo = 0, hi = (1u << BITS) - 1u;
+    for (int it = 0; it < BITS; it++) {
         const unsigned mid = (lo + hi) >> 1;
         int c = 0;
 #pragma unroll
@@ -41,7 +42,9 @@ __device__ __forceinline__ unsigned kth_smallest(const unsigned (&v)[PER_LANE], 
     return lo;
 }
 
-__global__ void __launch_bounds__(256) k7_mexican_hat(const uint16_t* __restrict__ img, int H, int W,
+// PX: uint16_t, or uint32_t for FSQ_PIXELS_U32 frames (values < 2^31: the search runs over 31 bits)
+template <typename PX>
+__global__ void __launch_bounds__(256) k7_mexican_hat(const PX* __restrict__ img, int H, int W,
                                                        const int32_t* __restrict__ fhw, long long n, int brim, int radius,
                                                        double* __restrict__ out)
 {
@@ -52,14 +55,15 @@ __global__ void __launch_bounds__(256) k7_mexican_hat(const uint16_t* __restrict
     const int r0 = max(0, h - radius), r1 = min(H, h + radius + 1);
     const int c0 = max(0, w - radius), c1 = min(W, w + radius + 1);
     const int hc = max(r1 - r0, 0), wc = max(c1 - c0, 0), npx = hc * wc, diameter = 2 * radius + 1;
-    const uint16_t* base = img + ((size_t)f * H) * W;
+    constexpr int BITS = sizeof(PX) == 2 ? 16 : 31;
+    const PX* base = img + ((size_t)f * H) * W;
     unsigned v[PER_LANE];
     long long crown = 0;
     int ncrown = 0, nbrim = 0;
 #pragma unroll
     for (int t = 0; t < PER_LANE; t++) {
         const int i = lane + 64 * t;
-        v[t] = 0x10000u;                                    // not a brim pixel: above every uint16
+        v[t] = 1u << BITS;                                  // not a brim pixel: above every pixel value
         if (i < npx) {
             const int hh = i / wc, ww = i - hh * wc;
             const unsigned p = base[(size_t)(r0 + hh) * W + (c0 + ww)];
@@ -73,14 +77,15 @@ __global__ void __launch_bounds__(256) k7_mexican_hat(const uint16_t* __restrict
     nbrim = wave_sum_i(nbrim);
     double med;
     if (nbrim == 0) med = __builtin_nan("");
-    else if (nbrim & 1) med = (double)kth_smallest(v, nbrim / 2);
-    else med = ((double)kth_smallest(v, nbrim / 2 - 1) + (double)kth_smallest(v, nbrim / 2)) / 2.0;
+    else if (nbrim & 1) med = (double)kth_smallest<BITS>(v, nbrim / 2);
+    else med = ((double)kth_smallest<BITS>(v, nbrim / 2 - 1) + (double)kth_smallest<BITS>(v, nbrim / 2)) / 2.0;
     if (lane == 0) out[spot] = (double)crown - (double)ncrown * med;
 }
 
 // Any radius (round 4: the register form above holds 31 x 31 windows; the reference has no limit, flexlibrary.py:172-210): the
 // same arithmetic with the window re-read from memory (it stays in L1 / L2) for every step of the binary search.
-__global__ void __launch_bounds__(256) k7_mexican_hat_any(const uint16_t* __restrict__ img, int H, int W,
+template <typename PX>
+__global__ void __launch_bounds__(256) k7_mexican_hat_any(const PX* __restrict__ img, int H, int W,
                                                            const int32_t* __restrict__ fhw, long long n, int brim, int radius,
                                                            double* __restrict__ out)
 {
@@ -91,7 +96,8 @@ __global__ void __launch_bounds__(256) k7_mexican_hat_any(const uint16_t* __rest
     const int r0 = max(0, h - radius), r1 = min(H, h + radius + 1);
     const int c0 = max(0, w - radius), c1 = min(W, w + radius + 1);
     const int hc = max(r1 - r0, 0), wc = max(c1 - c0, 0), npx = hc * wc, diameter = 2 * radius + 1;
-    const uint16_t* base = img + ((size_t)f * H) * W;
+    constexpr int BITS = sizeof(PX) == 2 ? 16 : 31;
+    const PX* base = img + ((size_t)f * H) * W;
     auto in_crown = [&](int hh, int ww) { return (brim <= hh) && (hh < diameter - brim) && (brim <= ww) && (ww < diameter - brim); };
     long long crown = 0;
     int ncrown = 0, nbrim = 0;
@@ -104,8 +110,8 @@ __global__ void __launch_bounds__(256) k7_mexican_hat_any(const uint16_t* __rest
     ncrown = wave_sum_i(ncrown);
     nbrim = wave_sum_i(nbrim);
     auto kth = [&](int rank) {           // smallest value x with #{brim <= x} >= rank + 1
-        unsigned lo = 0, hi = 65535;
-        for (int it = 0; it < 16; it++) {
+        unsigned lo = 0, hi = (1u << BITS) - 1u;
+        for (int it = 0; it < BITS; it++) {
             const unsigned mid = (lo + hi) >> 1;
             int c = 0;
             for (int i = lane; i < npx; i += 64) {
@@ -126,8 +132,9 @@ __global__ void __launch_bounds__(256) k7_mexican_hat_any(const uint16_t* __rest
 
 }  // namespace
 
-extern "C" int fsq_mexican_hat(const uint16_t* d_img, int n_fields, int H, int W, const int32_t* d_fhw, int64_t n,
-                               int brim_size, int radius, double* d_out, void* stream)
+template <typename PX>
+static int mexican_hat_launch(const PX* d_img, int n_fields, int H, int W, const int32_t* d_fhw, int64_t n, int brim_size, int radius,
+                              double* d_out, void* stream)
 {
     if (n < 0 || n_fields < 1 || H < 1 || W < 1 || brim_size < 0 || radius < 0) return FSQ_EINVAL;
     if (radius > 16383) return FSQ_EINVAL;                        // ((2 r + 1)^2 must fit an int)
@@ -135,11 +142,23 @@ extern "C" int fsq_mexican_hat(const uint16_t* d_img, int n_fields, int H, int W
     if (!d_img || !d_fhw || !d_out) return FSQ_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (radius <= MAXR)
-        hipLaunchKernelGGL(k7_mexican_hat, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, d_img, H, W, d_fhw, (long long)n,
+        hipLaunchKernelGGL(k7_mexican_hat<PX>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, d_img, H, W, d_fhw, (long long)n,
                            brim_size, radius, d_out);
     else
-        hipLaunchKernelGGL(k7_mexican_hat_any, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, d_img, H, W, d_fhw, (long long)n,
+        hipLaunchKernelGGL(k7_mexican_hat_any<PX>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, d_img, H, W, d_fhw, (long long)n,
                            brim_size, radius, d_out);
     FSQ_HIP_CHECK(hipGetLastError());
     return FSQ_OK;
+}
+
+extern "C" int fsq_mexican_hat(const uint16_t* d_img, int n_fields, int H, int W, const int32_t* d_fhw, int64_t n,
+                               int brim_size, int radius, double* d_out, void* stream)
+{
+    return mexican_hat_launch(d_img, n_fields, H, W, d_fhw, n, brim_size, radius, d_out, stream);
+}
+
+extern "C" int fsq_mexican_hat_u32(const uint32_t* d_img, int n_fields, int H, int W, const int32_t* d_fhw, int64_t n,
+                                   int brim_size, int radius, double* d_out, void* stream)
+{
+    return mexican_hat_launch(d_img, n_fields, H, W, d_fhw, n, brim_size, radius, d_out, stream);
 }

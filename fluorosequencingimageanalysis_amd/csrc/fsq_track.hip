@@ -231,12 +231,13 @@ __global__ void __launch_bounds__(256) k8_track(const int32_t* __restrict__ hw, 
 __device__ __forceinline__ long trk_slice_bound(long v, long n) { if (v < 0) { v += n; if (v < 0) v = 0; } else if (v > n) v = n; return v; }
 __device__ __forceinline__ bool trk_spot_fits(long h, long w, int H, int W) { return 0 <= h - 2 && h + 2 < H && 0 <= w - 2 && w + 2 < W; }
 
-__device__ double trk_illumina_s_n(const uint16_t* __restrict__ img, int W, long h, long w)
+template <typename PX>
+__device__ double trk_illumina_s_n(const PX* __restrict__ img, int W, long h, long w)
 {
     double op[16];
     int t = 0;
     unsigned mx = 0;
-    const uint16_t* base = img + (size_t)(h - 2) * W + (w - 2);
+    const PX* base = img + (size_t)(h - 2) * W + (w - 2);
     for (int a = 0; a < 5; a++)
         for (int b = 0; b < 5; b++) { const unsigned v = base[(size_t)a * W + b]; mx = v > mx ? v : mx; }
     for (int b = 0; b < 5; b++) op[t++] = (double)base[b];
@@ -252,7 +253,9 @@ __device__ double trk_illumina_s_n(const uint16_t* __restrict__ img, int W, long
     return ((double)mx - mean) / __builtin_sqrt(res / 16.0);
 }
 
-__global__ void __launch_bounds__(256) k9_centroid_track(const uint16_t* __restrict__ frames, int n_fields, int F, int H, int W,
+// PX: uint16_t, or uint32_t for FSQ_PIXELS_U32 frames (values < 2^31; the window sums stay far below 2^64 for any radius an image allows)
+template <typename PX>
+__global__ void __launch_bounds__(256) k9_centroid_track(const PX* __restrict__ frames, int n_fields, int F, int H, int W,
                                                          const int32_t* __restrict__ init_hw, const int32_t* __restrict__ spot_field,
                                                          long long n, int R, double s_n_cutoff, const long long* __restrict__ offsets,
                                                          int32_t* __restrict__ out_hw, uint8_t* __restrict__ present,
@@ -267,7 +270,7 @@ __global__ void __launch_bounds__(256) k9_centroid_track(const uint16_t* __restr
     const int D = 2 * R + 1;
     bool failed = false;
     for (int f = 1; f < F; f++) {
-        const uint16_t* img = frames + ((size_t)fld * F + f) * H * W;
+        const PX* img = frames + ((size_t)fld * F + f) * H * W;
         const long oh = ph - (offsets ? (long)offsets[((size_t)fld * F + f) * 2] : 0);
         const long ow = pw - (offsets ? (long)offsets[((size_t)fld * F + f) * 2 + 1] : 0);
         const long h0 = trk_slice_bound(oh - R, H), h1 = trk_slice_bound(oh + R + 1, H);
@@ -340,21 +343,40 @@ extern "C" int fsq_greedy_tracking(const int32_t* d_hw, const int32_t* d_field_s
     return FSQ_OK;
 }
 
+template <typename PX>
+static int centroid_tracking_launch(const PX* d_frames, int n_fields, int n_frames, int H, int W, const int32_t* d_init_hw,
+                                    const int32_t* d_spot_field, int64_t n, int search_radius, double s_n_cutoff,
+                                    const int64_t* d_offsets, int32_t* d_out_hw, uint8_t* d_present, int32_t* d_n_errors, void* stream)
+{
+    if (n_fields < 1 || n_frames < 1 || H < 1 || W < 1 || n < 0 || search_radius < 0) return FSQ_EINVAL;
+    if (!d_frames || !d_n_errors || (n > 0 && (!d_init_hw || !d_spot_field || !d_out_hw || !d_present))) return FSQ_EINVAL;
+    if (sizeof(PX) == 4 && search_radius > 512) return FSQ_ENOTIMPL;           // (the weighted sums of a window - D^3 x 2^31 at most - must fit 63 bits, like scipy's int64 sums)
+    hipStream_t s = (hipStream_t)stream;
+    FSQ_HIP_CHECK(hipMemsetAsync(d_n_errors, 0, sizeof(int32_t), s));
+    if (n > 0)
+        hipLaunchKernelGGL(k9_centroid_track<PX>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_frames, n_fields, n_frames, H, W,
+                           d_init_hw, d_spot_field, (long long)n, search_radius, s_n_cutoff, (const long long*)d_offsets, d_out_hw,
+                           d_present, d_n_errors);
+    FSQ_HIP_CHECK(hipGetLastError());
+    return FSQ_OK;
+}
+
 extern "C" int fsq_centroid_tracking(const uint16_t* d_frames, int n_fields, int n_frames, int H, int W, const int32_t* d_init_hw,
                                      const int32_t* d_spot_field, int64_t n, int search_radius, double s_n_cutoff,
                                      const int64_t* d_offsets, int32_t* d_out_hw, uint8_t* d_present, int32_t* d_n_errors,
                                      void* stream)
 {
-    if (n_fields < 1 || n_frames < 1 || H < 1 || W < 1 || n < 0 || search_radius < 0) return FSQ_EINVAL;
-    if (!d_frames || !d_n_errors || (n > 0 && (!d_init_hw || !d_spot_field || !d_out_hw || !d_present))) return FSQ_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    FSQ_HIP_CHECK(hipMemsetAsync(d_n_errors, 0, sizeof(int32_t), s));
-    if (n > 0)
-        hipLaunchKernelGGL(k9_centroid_track, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_frames, n_fields, n_frames, H, W,
-                           d_init_hw, d_spot_field, (long long)n, search_radius, s_n_cutoff, (const long long*)d_offsets, d_out_hw,
-                           d_present, d_n_errors);
-    FSQ_HIP_CHECK(hipGetLastError());
-    return FSQ_OK;
+    return centroid_tracking_launch(d_frames, n_fields, n_frames, H, W, d_init_hw, d_spot_field, n, search_radius, s_n_cutoff,
+                                    d_offsets, d_out_hw, d_present, d_n_errors, stream);
+}
+
+extern "C" int fsq_centroid_tracking_u32(const uint32_t* d_frames, int n_fields, int n_frames, int H, int W, const int32_t* d_init_hw,
+                                         const int32_t* d_spot_field, int64_t n, int search_radius, double s_n_cutoff,
+                                         const int64_t* d_offsets, int32_t* d_out_hw, uint8_t* d_present, int32_t* d_n_errors,
+                                         void* stream)
+{
+    return centroid_tracking_launch(d_frames, n_fields, n_frames, H, W, d_init_hw, d_spot_field, n, search_radius, s_n_cutoff,
+                                    d_offsets, d_out_hw, d_present, d_n_errors, stream);
 }
 
 extern "C" int fsq_selftest_dnrm2(const double* d_dh, const double* d_dw, int64_t n, double* d_out, void* stream)

@@ -83,6 +83,13 @@ def as_pixel_fields(image, wide=False):
     return as_u16_fields(a), N.PIXELS_U16
 
 
+def as_integer_fields(image):
+    """-> (pixel words, PIXELS_U16 or PIXELS_U32) for the entry points that read VALUES only (photometry, centroid tracking): like
+    as_pixel_fields, but a float16 image is truncated to integers like any other float image instead of being uploaded as binary16 words."""
+    a = np.asarray(image)
+    return as_pixel_fields(a.astype(np.float32) if a.dtype == np.float16 else a)
+
+
 def quantise_f16(images):
     """Integer pixels -> (float16 image, scale): scaled down just enough to fit binary16's range (max 65504), then
     rounded to binary16 ("image pre-scaled to fit fp16")."""

@@ -103,12 +103,12 @@ def _track_launch(torch, dev, L, hw, start, counts, off, n_fields, F, H, W, cand
 def centroid_track_fields(frames, init_hw, spot_field=None, search_radius=3, s_n_cutoff=3.0, offsets=None, device=None):
     """Luminosity-centroid tracking of many spots in many fields in one launch (fsq_centroid_tracking).
 
-    frames uint16[n_fields, F, H, W] (or [F, H, W] for one field); init_hw int[n, 2]; spot_field int[n] (default: all in
+    frames integer[n_fields, F, H, W] (or [F, H, W] for one field; values below 2^31, beyond 65 535: fsq_centroid_tracking_u32); init_hw int[n, 2]; spot_field int[n] (default: all in
     field 0); offsets whole-pixel (d_h, d_w)[n_fields, F, 2] or None.  -> (hw int32[n, F, 2], present bool[n, F]);
     raises ValueError where the reference does (a search window that sums to zero)."""
     torch = _engine._torch()
     dev = torch.device(device or ("cuda:%d" % torch.cuda.current_device()))
-    fr = _engine.as_u16_fields(frames)
+    fr, fmt = _engine.as_integer_fields(frames)
     if fr.ndim == 3:
         fr = fr[None]
     if fr.ndim != 4:
@@ -125,12 +125,12 @@ def centroid_track_fields(frames, init_hw, spot_field=None, search_radius=3, s_n
         if not np.array_equal(off, np.rint(off)):
             raise TypeError("slice indices must be integers")       # what the reference's image slicing raises (:1223)
         d_off = torch.from_numpy(np.ascontiguousarray(off.astype(np.int64).reshape(n_fields, F, 2))).to(dev)
-    d_fr = _engine.to_device_u16(fr, dev)
+    d_fr = _engine.to_device_pixels(fr, fmt, dev)
     d_hw, d_sf = torch.from_numpy(hw).to(dev), torch.from_numpy(sf).to(dev)
     d_out = torch.empty((max(n, 1), F, 2), dtype=torch.int32, device=dev)
     d_pres = torch.empty((max(n, 1), F), dtype=torch.uint8, device=dev)
     d_err = torch.zeros(1, dtype=torch.int32, device=dev)
-    rc = N.lib().fsq_centroid_tracking(d_fr.data_ptr(), n_fields, F, H, W, d_hw.data_ptr(), d_sf.data_ptr(), n, int(search_radius),
+    rc = (N.lib().fsq_centroid_tracking_u32 if fmt == N.PIXELS_U32 else N.lib().fsq_centroid_tracking)(d_fr.data_ptr(), n_fields, F, H, W, d_hw.data_ptr(), d_sf.data_ptr(), n, int(search_radius),
                                        float(s_n_cutoff), d_off.data_ptr() if d_off is not None else None, d_out.data_ptr(),
                                        d_pres.data_ptr(), d_err.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
     N.check(rc, "fsq_centroid_tracking")

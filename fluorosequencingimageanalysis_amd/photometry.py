@@ -10,12 +10,12 @@ from . import engine as _engine
 def mexican_hat_photometry_metric(images, spots, brim_size=6, radius=9):
     """Spot.mexican_hat_photometry_metric (flexlibrary.py:172-210) for many spots at once.
 
-    images: one 2-D integer image or a stack [n_fields, H, W] (values in [0, 65535]);
+    images: one 2-D integer image or a stack [n_fields, H, W] (values in [0, 2^31); beyond 65 535: fsq_mexican_hat_u32);
     spots:  int array [n, 2] of (h, w) centres for a single image, or [n, 3] of (field, h, w) for a stack.
     Returns float64[n]: sum(crown pixels) - len(crown) * median(brim pixels) over the (2*radius+1)^2 window, clipped at the
     image borders exactly as Spot.image_slice does (return_invalid=True behaviour)."""
     torch = _engine._torch()
-    imgs = _engine.as_u16_fields(images)
+    imgs, fmt = _engine.as_integer_fields(images)
     if imgs.ndim == 2:
         imgs = imgs[None]
     if imgs.ndim != 3:
@@ -32,10 +32,10 @@ def mexican_hat_photometry_metric(images, spots, brim_size=6, radius=9):
         raise ValueError("field index out of range")
     if len(sp) == 0:
         return np.zeros(0)
-    d_img = _engine.to_device_u16(imgs)
+    d_img = _engine.to_device_pixels(imgs, fmt)
     d_sp = torch.from_numpy(np.ascontiguousarray(sp.astype(np.int32))).to(d_img.device)
     d_out = torch.empty(len(sp), dtype=torch.float64, device=d_img.device)
-    rc = N.lib().fsq_mexican_hat(d_img.data_ptr(), n_fields, H, W, d_sp.data_ptr(), len(sp), int(brim_size), int(radius),
+    rc = (N.lib().fsq_mexican_hat_u32 if fmt == N.PIXELS_U32 else N.lib().fsq_mexican_hat)(d_img.data_ptr(), n_fields, H, W, d_sp.data_ptr(), len(sp), int(brim_size), int(radius),
                                  d_out.data_ptr(), torch.cuda.current_stream(d_img.device).cuda_stream)
     N.check(rc, "fsq_mexican_hat")
     return d_out.cpu().numpy()

@@ -74,8 +74,8 @@ typedef struct FsqRow {
                             * is handed.  Taken by fsq_detect, fsq_fit_candidates (| FSQ_PIXELS_U32_FLAG), fsq_find_peptides (records of
                             * FSQ_PEAK_RECORD_BYTES_U32 bytes), a fit queue created for them (fsq_fitq_create with mode |
                             * FSQ_PIXELS_U32_FLAG: such a queue takes uint32 batches only, any other queue none) and fsq_fit_images /
-                            * fsq_consolidate / fsq_kept_rows (format-independent); the single-precision mode and the photometry /
-                            * tracking entry points stay 16-bit (FSQ_ENOTIMPL / uint16 arguments). */
+                            * fsq_consolidate / fsq_kept_rows (format-independent); photometry and centroid tracking have _u32 twins
+                            * (fsq_mexican_hat_u32, fsq_centroid_tracking_u32); only the single-precision mode stays 16-bit (FSQ_ENOTIMPL). */
 
 #define FSQ_MAX_KSIZE 15                           /* largest correlation matrix / median window side (round 4: was 9) */
 typedef struct FsqDetectParams {
@@ -255,6 +255,9 @@ int fsq_phase_correlate(const void* d_ref, const void* d_reg, int dtype, int n_p
  */
 int fsq_mexican_hat(const uint16_t* d_img, int n_fields, int H, int W, const int32_t* d_fhw, int64_t n,
                     int brim_size, int radius, double* d_out, void* stream);
+/* the same on FSQ_PIXELS_U32 frames (uint32[n_fields][H][W], values < 2^31) */
+int fsq_mexican_hat_u32(const uint32_t* d_img, int n_fields, int H, int W, const int32_t* d_fhw, int64_t n,
+                        int brim_size, int radius, double* d_out, void* stream);
 
 /*
  * Greedy particle tracking of the peak tables across the frames of a field:
@@ -301,6 +304,10 @@ int fsq_greedy_tracking(const int32_t* d_hw, const int32_t* d_field_start, const
 int fsq_centroid_tracking(const uint16_t* d_frames, int n_fields, int n_frames, int H, int W, const int32_t* d_init_hw,
                           const int32_t* d_spot_field, int64_t n, int search_radius, double s_n_cutoff,
                           const int64_t* d_offsets, int32_t* d_out_hw, uint8_t* d_present, int32_t* d_n_errors, void* stream);
+/* the same on FSQ_PIXELS_U32 frames (uint32[n_fields][n_frames][H][W], values < 2^31; search_radius <= 512) */
+int fsq_centroid_tracking_u32(const uint32_t* d_frames, int n_fields, int n_frames, int H, int W, const int32_t* d_init_hw,
+                              const int32_t* d_spot_field, int64_t n, int search_radius, double s_n_cutoff,
+                              const int64_t* d_offsets, int32_t* d_out_hw, uint8_t* d_present, int32_t* d_n_errors, void* stream);
 /* fsq_selftest_dnrm2: the tracking kernel's pair distance (OpenBLAS dnrm2 in x87 extended precision, restated in
  * integer arithmetic, csrc/fsq_x87.h) for caller-supplied displacement vectors; d_out[i] = dnrm2((d_dh[i], d_dw[i])). */
 int fsq_selftest_dnrm2(const double* d_dh, const double* d_dw, int64_t n, double* d_out, void* stream);

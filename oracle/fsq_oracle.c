@@ -900,28 +900,36 @@ double fsq_o_numpy_sum(const double *a, long n) { return numpy_sum(a, (size_t)n)
  * the crown when brim <= row < diameter - brim and the same for the column, to the brim otherwise;
  * photometry = sum(crown) - len(crown) * numpy.median(brim).  Pixels are integers, so everything is exact:
  * the median of an even count is the mean of the two middle values, of an empty brim nan. */
-static int cmp_u16(const void *a, const void *b) { return (int)*(const uint16_t *)a - (int)*(const uint16_t *)b; }
-double fsq_o_mexican_hat(const uint16_t *img, int H, int W, int h, int w, int brim, int radius)
+static double mexican_hat_any(const void *img, int wide, int H, int W, int h, int w, int brim, int radius)
 {
     int r0 = h - radius < 0 ? 0 : h - radius, r1 = h + radius + 1 > H ? H : h + radius + 1;
     int c0 = w - radius < 0 ? 0 : w - radius, c1 = w + radius + 1 > W ? W : w + radius + 1;
     int diameter = 2 * radius + 1;
     long long crown = 0, ncrown = 0;
     int nb = 0, cap = (r1 > r0 && c1 > c0) ? (r1 - r0) * (c1 - c0) : 0;
-    uint16_t *b = (uint16_t *)malloc((cap > 0 ? cap : 1) * sizeof(uint16_t));
+    int64_t *b = (int64_t *)malloc((cap > 0 ? cap : 1) * sizeof(int64_t));
     for (int r = r0; r < r1; r++)
         for (int c = c0; c < c1; c++) {
             int hh = r - r0, ww = c - c0;
-            uint16_t p = img[(size_t)r * W + c];
+            int64_t p = px_at(img, wide, (size_t)r * W + c);
             if (brim <= hh && hh < diameter - brim && brim <= ww && ww < diameter - brim) { crown += p; ncrown++; }
             else b[nb++] = p;
         }
     double med;
     if (nb == 0) med = NAN;
     else {
-        qsort(b, nb, sizeof(uint16_t), cmp_u16);
+        qsort(b, nb, sizeof(int64_t), cmp_i64);
         med = (nb & 1) ? (double)b[nb / 2] : ((double)b[nb / 2 - 1] + (double)b[nb / 2]) / 2.0;
     }
     free(b);
     return (double)crown - (double)ncrown * med;
+}
+double fsq_o_mexican_hat(const uint16_t *img, int H, int W, int h, int w, int brim, int radius)
+{
+    return mexican_hat_any(img, 0, H, W, h, w, brim, radius);
+}
+/* the same on uint32 pixels (values < 2^31) */
+double fsq_o_mexican_hat_u32(const uint32_t *img, int H, int W, int h, int w, int brim, int radius)
+{
+    return mexican_hat_any(img, 1, H, W, h, w, brim, radius);
 }

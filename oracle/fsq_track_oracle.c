@@ -181,8 +181,14 @@ static int spot_fits(long h, long w, int size, int H, int W)               /* Sp
     return 0 <= h - r && h + r < H && 0 <= w - r && w + r < W;
 }
 
-int fsq_o_centroid_tracking(const uint16_t* frames, int F, int H, int W, const int32_t* init_hw, int n, int size,
-                            int search_radius, double s_n_cutoff, const int64_t* offsets, int32_t* out_hw, uint8_t* present)
+/* pixel k of a stack stored as uint16 (wide = 0) or uint32 (wide = 1, values < 2^31) */
+static inline uint64_t trk_px(const void* frames, int wide, size_t k)
+{
+    return wide ? (uint64_t)((const uint32_t*)frames)[k] : (uint64_t)((const uint16_t*)frames)[k];
+}
+
+static int centroid_tracking_any(const void* frames, int wide, int F, int H, int W, const int32_t* init_hw, int n, int size,
+                                 int search_radius, double s_n_cutoff, const int64_t* offsets, int32_t* out_hw, uint8_t* present)
 {
     if (size != 5 || search_radius < 0) return -2;
     const int R = search_radius, D = 2 * R + 1;
@@ -191,25 +197,27 @@ int fsq_o_centroid_tracking(const uint16_t* frames, int F, int H, int W, const i
         out_hw[((size_t)i * F) * 2] = (int32_t)ph; out_hw[((size_t)i * F) * 2 + 1] = (int32_t)pw;
         present[(size_t)i * F] = 1;
         for (int f = 1; f < F; f++) {
-            const uint16_t* img = frames + (size_t)f * H * W;
+            const size_t img0 = (size_t)f * H * W;                        /* frame f starts at pixel img0 */
             const long oh = ph - (offsets ? offsets[2 * f] : 0), ow = pw - (offsets ? offsets[2 * f + 1] : 0);
             /* numpy slice image[oh-R : oh+R+1, ow-R : ow+R+1] (negative bounds wrap, flexlibrary.py:1223-1226) */
             const long h0 = slice_bound(oh - R, H), h1 = slice_bound(oh + R + 1, H);
             const long w0 = slice_bound(ow - R, W), w1 = slice_bound(ow + R + 1, W);
             int found = 0; long nh = 0, nw = 0;
             if (h1 - h0 == D && w1 - w0 == D) {
-                uint64_t norm = 0; double sh = 0.0, sw = 0.0;                 /* scipy.ndimage.center_of_mass: exact sums */
+                /* scipy.ndimage.center_of_mass on the int64 window: integer sums (exact), then one true division per axis */
+                uint64_t norm = 0, sh = 0, sw = 0;
                 for (int a = 0; a < D; a++)
                     for (int b = 0; b < D; b++) {
-                        const uint16_t v = img[(size_t)(h0 + a) * W + (w0 + b)];
-                        norm += v; sh += (double)v * (double)a; sw += (double)v * (double)b;
+                        const uint64_t v = trk_px(frames, wide, img0 + (size_t)(h0 + a) * W + (w0 + b));
+                        norm += v; sh += v * (uint64_t)a; sw += v * (uint64_t)b;
                     }
                 if (norm == 0) return -1;
-                const double ch = sh / (double)norm, cw = sw / (double)norm;
+                const double ch = (double)sh / (double)norm, cw = (double)sw / (double)norm;
                 const long rh = py2_round((ch + (double)oh) - (double)R), rw = py2_round((cw + (double)ow) - (double)R);
                 if (spot_fits(rh, rw, size, H, W)) {
                     int64_t roi[25];
-                    for (int a = 0; a < 5; a++) for (int b = 0; b < 5; b++) roi[a * 5 + b] = img[(size_t)(rh - 2 + a) * W + (rw - 2 + b)];
+                    for (int a = 0; a < 5; a++)
+                        for (int b = 0; b < 5; b++) roi[a * 5 + b] = (int64_t)trk_px(frames, wide, img0 + (size_t)(rh - 2 + a) * W + (rw - 2 + b));
                     found = 1; nh = rh; nw = rw;
                     if (fsq_o_illumina_s_n(roi) < s_n_cutoff) {               /* :1248-1259: same coordinates as the prior spot */
                         if (spot_fits(ph, pw, size, H, W)) { nh = ph; nw = pw; } else found = 0;
@@ -223,4 +231,17 @@ int fsq_o_centroid_tracking(const uint16_t* frames, int F, int H, int W, const i
         }
     }
     return 0;
+}
+
+int fsq_o_centroid_tracking(const uint16_t* frames, int F, int H, int W, const int32_t* init_hw, int n, int size,
+                            int search_radius, double s_n_cutoff, const int64_t* offsets, int32_t* out_hw, uint8_t* present)
+{
+    return centroid_tracking_any(frames, 0, F, H, W, init_hw, n, size, search_radius, s_n_cutoff, offsets, out_hw, present);
+}
+
+/* the same on uint32 frames (values < 2^31) */
+int fsq_o_centroid_tracking_u32(const uint32_t* frames, int F, int H, int W, const int32_t* init_hw, int n, int size,
+                                int search_radius, double s_n_cutoff, const int64_t* offsets, int32_t* out_hw, uint8_t* present)
+{
+    return centroid_tracking_any(frames, 1, F, H, W, init_hw, n, size, search_radius, s_n_cutoff, offsets, out_hw, present);
 }

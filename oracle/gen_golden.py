@@ -9,7 +9,7 @@ fluorosequencingimageanalysis_amd/synth.py.  The .npz files hold DATA only
 
 Usage (about 4 minutes on 8 cores):
   NPY_DISABLE_CPU_FEATURES="AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL AVX512_SPR" \
-      python oracle/gen_golden.py [--only fields|reg|kat|phot|phot_wide|degen|params|tiny|wide|textbook|io|loader|track|track_long|centroid]
+      python oracle/gen_golden.py [--only fields|reg|kat|phot|phot_wide|degen|params|tiny|wide|textbook|io|loader|track|track_long|centroid|centroid_wide]
 
 Golden sets: G1 per-ROI fits, G2 candidate lists, G3 full
 find_peptides tables, G4 phase_correlate tuples, G5 known-answer tests.
@@ -419,6 +419,17 @@ def gen_photometry_wide():
             vals.append(float(sp.mexican_hat_photometry_metric(brim_size=int(brim), radius=int(radius))))
         out["mexican_hat_b%d_r%d" % (brim, radius)] = np.array(vals)
         print("photometry_wide", (int(brim), int(radius)), len(vals), "spots", flush=True)
+    # ... and on the same field with pixel values beyond 16 bits (x 300: up to 24 bits)
+    parent.image = img.astype(np.int64) * 300
+    out["pixel_scale"] = np.int64(300)
+    for brim, radius in ((6, 9), (10, 40)):
+        vals = []
+        for h, w in hw:
+            sp = fl.Spot.__new__(fl.Spot)
+            sp.parent_Image, sp.h, sp.w, sp.size, sp.gaussian_fit = parent, h, w, 5, None
+            vals.append(float(sp.mexican_hat_photometry_metric(brim_size=int(brim), radius=int(radius))))
+        out["scaled_mexican_hat_b%d_r%d" % (brim, radius)] = np.array(vals)
+        print("photometry_wide, pixels x 300", (brim, radius), len(vals), "spots", flush=True)
     np.savez_compressed(os.path.join(GOLD, "photometry_wide.npz"), **out)
 
 
@@ -575,7 +586,19 @@ def centroid_cases():
     return cases
 
 
-def gen_centroid():
+def centroid_wide_cases():
+    """The centroid-tracking cases with pixel values beyond 16 bits (uint32 frames) -> tests/golden/centroid_tracking_wide.npz."""
+    base = centroid_cases()
+    frames, init, offs, sr, cut = base["stack160_registered"]
+    wide = frames.astype(np.uint32) * 517 + 70000
+    cases = {"stack160_wide_registered": (wide, init, offs, sr, cut),
+             "stack160_wide_strict_r2": (wide, init, offs, 2, 12.0)}
+    frames, init, offs, sr, cut = base["borders"]
+    cases["borders_wide"] = (np.minimum(frames.astype(np.int64) * 600000, 2 ** 31 - 1).astype(np.uint32), init, offs, sr, cut)
+    return cases
+
+
+def gen_centroid(cases=None, out_name="centroid_tracking.npz"):
     """N4 goldens: Experiment.luminosity_centroid_particle_tracking of the reference (flexlibrary.py:1262-1317)."""
     import refload
     ref = refload.load_flexlibrary(_ref())
@@ -585,7 +608,7 @@ def gen_centroid():
         def __init__(self, a):
             self.image = a
     out = {"names": []}
-    for name, (frames, init_hw, offsets, sr, cut) in centroid_cases().items():
+    for name, (frames, init_hw, offsets, sr, cut) in (cases if cases is not None else centroid_cases()).items():
         imgs = [Img(f) for f in frames]
         spots = [fl.Spot(imgs[0], int(h), int(w), 5) for h, w in init_hw]
         tracks = fl.Experiment.luminosity_centroid_particle_tracking(
@@ -600,7 +623,7 @@ def gen_centroid():
         out[name + "_hw"] = hw
         print(name, "spots", len(spots), "present fraction", float((hw[:, :, 0] >= 0).mean()), flush=True)
     out["names"] = np.array(out["names"])
-    np.savez_compressed(os.path.join(GOLD, "centroid_tracking.npz"), **out)
+    np.savez_compressed(os.path.join(GOLD, out_name), **out)
 
 
 def gen_io():
@@ -705,6 +728,8 @@ def main():
         gen_tracking(tracking_long_cases(), "tracking_long.npz")
     if a.only in ("", "centroid"):
         gen_centroid()
+    if a.only in ("", "centroid_wide"):
+        gen_centroid(centroid_wide_cases(), "centroid_tracking_wide.npz")
     if a.only in ("", "loader"):
         gen_loader()
     if a.only in ("", "io"):

@@ -157,12 +157,13 @@ def phase_correlate(ref, reg, upsample_factor=1):
 
 def mexican_hat(img, hw, brim_size=6, radius=9):
     """Spot.mexican_hat_photometry_metric (flexlibrary.py:172-210) for integer spot centres hw[n, 2]."""
-    img = np.ascontiguousarray(img, dtype=np.uint16)
+    img, wide = _pixels(img)
     H, W = img.shape
     L = lib()
-    L.fsq_o_mexican_hat.restype = ctypes.c_double
-    L.fsq_o_mexican_hat.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 6
-    return np.array([L.fsq_o_mexican_hat(_p(img), H, W, int(h), int(w), int(brim_size), int(radius)) for h, w in hw])
+    f = L.fsq_o_mexican_hat_u32 if wide else L.fsq_o_mexican_hat
+    f.restype = ctypes.c_double
+    f.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 6
+    return np.array([f(_p(img), H, W, int(h), int(w), int(brim_size), int(radius)) for h, w in hw])
 
 
 def gaussian_volume(fit7, scaling=10 ** 6):
@@ -214,7 +215,7 @@ def greedy_tracking(frame_hw, offsets, shape, candidate_radius=2, spot_radius=0.
 def centroid_tracking(frames, init_hw, search_radius=3, s_n_cutoff=3.0, offsets=None, size=5):
     """Experiment.luminosity_centroid_particle_tracking (flexlibrary.py:1262-1317) for one field:
     frames uint16[F, H, W], init_hw int[n, 2], offsets int[F, 2] or None -> (hw int32[n, F, 2], present bool[n, F])."""
-    frames = np.ascontiguousarray(frames, dtype=np.uint16)
+    frames, wide = _pixels(frames)
     F, H, W = frames.shape
     hw = np.ascontiguousarray(np.asarray(init_hw, dtype=np.int32).reshape(-1, 2))
     n = len(hw)
@@ -222,9 +223,10 @@ def centroid_tracking(frames, init_hw, search_radius=3, s_n_cutoff=3.0, offsets=
     out = np.zeros((n, F, 2), np.int32)
     present = np.zeros((n, F), np.uint8)
     L = lib()
-    L.fsq_o_centroid_tracking.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
-                                          ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-    rc = L.fsq_o_centroid_tracking(_p(frames), F, H, W, _p(hw), n, int(size), int(search_radius), float(s_n_cutoff),
+    f = L.fsq_o_centroid_tracking_u32 if wide else L.fsq_o_centroid_tracking
+    f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                  ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    rc = f(_p(frames), F, H, W, _p(hw), n, int(size), int(search_radius), float(s_n_cutoff),
                                    None if off is None else _p(off), _p(out), _p(present))
     if rc == -1:
         raise ValueError("cannot convert float NaN to integer")

@@ -44,6 +44,26 @@ def test_large_windows_equal_reference(env):
         exp = g["mexican_hat_b%d_r%d" % (brim, radius)]
         got = ph.mexican_hat_photometry_metric(img, g["hw"], brim_size=int(brim), radius=int(radius))
         assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.array_equal(got[~np.isnan(exp)], exp[~np.isnan(exp)]), (brim, radius)
+    wide = img.astype(np.int64) * int(g["pixel_scale"])             # pixel values beyond 16 bits: fsq_mexican_hat_u32
+    for brim, radius in ((6, 9), (10, 40)):
+        got = ph.mexican_hat_photometry_metric(wide, g["hw"], brim_size=brim, radius=radius)
+        assert np.array_equal(got, g["scaled_mexican_hat_b%d_r%d" % (brim, radius)]), (brim, radius)
+
+
+def test_wide_pixels_vs_oracle(env):
+    """uint32 frames (values up to 2^31 - 1): random spots incl. clipped windows, register and any-radius kernels, a stack."""
+    ph, pflib, synth, O = env
+    rng = np.random.default_rng(8)
+    imgs = np.stack([synth.make_field(40 + i, (96, 130), 20).astype(np.uint32) * int(k) for i, k in enumerate((3, 700, 32000))])
+    imgs[2, 50:60, 50:60] = 2 ** 31 - 1
+    sp = np.stack([rng.integers(0, 3, 300), rng.integers(-3, 99, 300), rng.integers(-3, 133, 300)], axis=1)
+    for brim, radius in ((6, 9), (0, 3), (3, 15), (6, 16), (10, 40)):
+        got = ph.mexican_hat_photometry_metric(imgs, sp, brim_size=brim, radius=radius)
+        exp = np.concatenate([O.mexican_hat(imgs[f], sp[sp[:, 0] == f][:, 1:], brim, radius) for f in range(3)])
+        order = np.concatenate([np.nonzero(sp[:, 0] == f)[0] for f in range(3)])
+        assert np.array_equal(np.isnan(got[order]), np.isnan(exp)), (brim, radius)
+        ok = ~np.isnan(exp)
+        assert np.array_equal(got[order][ok].view(np.uint64), exp[ok].view(np.uint64)), (brim, radius)
 
 
 def test_random_spots_and_shapes_vs_oracle(env):

@@ -39,6 +39,18 @@ def test_long_series_and_large_fields_equal_reference(env, case):
     assert nd == discarded and got.shape == traces.shape and np.array_equal(got, traces)
 
 
+@pytest.mark.parametrize("case", list(load_centroid_cases("centroid_tracking_wide.npz")), ids=lambda c: c[0])
+def test_centroid_tracking_of_wide_frames_equals_reference(env, case):
+    """uint32 frames with pixel values beyond 16 bits (fsq_centroid_tracking_u32) against the reference's recorded tracks
+    (tests/golden/centroid_tracking_wide.npz) and the oracle."""
+    torch, N, fl, O = env
+    name, frames, init, offsets, sr, cut, hw = case
+    got, present = fl.centroid_track_fields(frames, init, None, sr, cut, None if offsets is None else offsets[None])
+    assert np.array_equal(got, hw) and np.array_equal(present, hw[:, :, 0] >= 0)
+    o_hw, o_pr = O.centroid_tracking(frames, init, sr, cut, offsets)
+    assert np.array_equal(got, o_hw) and np.array_equal(present, o_pr)
+
+
 def test_tracking_batch_and_object_surface(env):
     """Many fields per launch (random layouts vs the oracle), and the Experiment.greedy_particle_tracking surface on
     Spot-like objects."""

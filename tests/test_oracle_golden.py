@@ -239,3 +239,7 @@ def test_photometry_with_large_windows_matches_reference():
         exp = g["mexican_hat_b%d_r%d" % (brim, radius)]
         got = O.mexican_hat(img, g["hw"], int(brim), int(radius))
         assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.array_equal(got[~np.isnan(exp)], exp[~np.isnan(exp)]), (brim, radius)
+    wide = img.astype(np.uint32) * int(g["pixel_scale"])            # pixel values beyond 16 bits (fsq_o_mexican_hat_u32)
+    assert int(wide.max()) > 65535
+    for brim, radius in ((6, 9), (10, 40)):
+        assert np.array_equal(O.mexican_hat(wide, g["hw"], brim, radius), g["scaled_mexican_hat_b%d_r%d" % (brim, radius)])

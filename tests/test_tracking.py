@@ -87,8 +87,8 @@ def test_x87_header_on_host(tmp_path):
     assert "bad=0" in out, out
 
 
-def load_centroid_cases():
-    g = np.load(os.path.join(GOLD, "centroid_tracking.npz"))
+def load_centroid_cases(file="centroid_tracking.npz"):
+    g = np.load(os.path.join(GOLD, file))
     for name in g["names"]:
         name = str(name)
         off = g[name + "_offsets"]
@@ -104,6 +104,15 @@ def test_oracle_centroid_tracking_equals_reference(case):
     got, present = O.centroid_tracking(frames, init, sr, cut, offsets)
     assert np.array_equal(got, hw)
     assert np.array_equal(present, hw[:, :, 0] >= 0)
+
+
+@pytest.mark.parametrize("case", list(load_centroid_cases("centroid_tracking_wide.npz")), ids=lambda c: c[0])
+def test_oracle_centroid_tracking_of_wide_frames_equals_reference(case):
+    """uint32 frames with pixel values beyond 16 bits (oracle/gen_golden.py --only centroid_wide)."""
+    name, frames, init, offsets, sr, cut, hw = case
+    assert frames.dtype == np.uint32 and int(frames.max()) > 65535
+    got, present = O.centroid_tracking(frames, init, sr, cut, offsets)
+    assert np.array_equal(got, hw) and np.array_equal(present, hw[:, :, 0] >= 0)
 
 
 def test_centroid_goldens_cover_the_cases():
