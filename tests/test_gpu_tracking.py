@@ -220,6 +220,15 @@ def test_centroid_tracking_batch_and_objects(env):
     for k in range(3):
         exp, ep = O.centroid_tracking(stack[k], init, sr, cut, offs[k])
         assert np.array_equal(got[fld == k], exp) and np.array_equal(present[fld == k], ep)
+    # the same fields as uint32 frames with values up to 2^31 - 1 (fsq_centroid_tracking_u32), other radii and cut-offs
+    wide = np.minimum(stack.astype(np.int64) * np.array([41, 9000, 300000])[:, None, None, None], 2 ** 31 - 1).astype(np.uint32)
+    for sr2, cut2 in ((3, 3.0), (1, 0.5), (6, 8.0)):
+        got, present = fl.centroid_track_fields(wide, pts, fld, sr2, cut2, offs)
+        for k in range(3):
+            exp, ep = O.centroid_tracking(wide[k], init, sr2, cut2, offs[k])
+            assert np.array_equal(got[fld == k], exp) and np.array_equal(present[fld == k], ep), (sr2, k)
+    with pytest.raises(NotImplementedError):
+        fl.centroid_track_fields(wide, pts, fld, 513, cut, offs)
 
     class Img(object):
         def __init__(self, a):
