@@ -1016,6 +1016,10 @@ class _IoPool:
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = dict(os.environ)
         env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+        # the workers decode / encode images and pickle: no linear algebra - numpy's BLAS must not start a thread per core in
+        # every one of them (on a 256-core host that is thousands of threads at start-up)
+        for k in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+            env.setdefault(k, "1")
         w = subprocess.Popen([sys.executable, "-m", "fluorosequencingimageanalysis_amd._io_worker"], stdin=subprocess.PIPE,
                              stdout=subprocess.PIPE, env=env)
         with self.lock:
