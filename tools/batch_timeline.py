@@ -20,10 +20,10 @@ def wrap(obj, name, label):
     inner = getattr(obj, name)
 
     def f(*a, **k):
-        t0 = time.perf_counter()
+        t0, c0 = time.perf_counter(), time.thread_time()
         r = inner(*a, **k)
-        with lock:
-            marks.append((t0, time.perf_counter(), label, threading.current_thread().name))
+        with lock:           # (thread_time: CPU time of this thread - far below the wall time means it waited, e.g. for the interpreter)
+            marks.append((t0, time.perf_counter(), "%s (cpu %.1f ms)" % (label, (time.thread_time() - c0) * 1e3), threading.current_thread().name))
         return r
     setattr(obj, name, f)
 
@@ -40,8 +40,8 @@ t1 = time.perf_counter()
 print("%d fields in %.3f s = %.0f fields/s" % (n, t1 - t0, n / (t1 - t0)))
 busy = {}
 for a, b, label, th in sorted(marks):
-    print("%7.1f .. %7.1f ms  %-9s %s" % ((a - t0) * 1e3, (b - t0) * 1e3, label, th))
-    busy[label] = busy.get(label, 0.0) + (b - a)
+    print("%7.1f .. %7.1f ms  %-24s %s" % ((a - t0) * 1e3, (b - t0) * 1e3, label, th))
+    busy[label.split(" (")[0]] = busy.get(label.split(" (")[0], 0.0) + (b - a)
 print({k: "%.1f ms" % (v * 1e3) for k, v in busy.items()})
 t2 = time.perf_counter()
 del out
