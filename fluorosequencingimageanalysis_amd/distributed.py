@@ -206,7 +206,7 @@ def find_peptides_sharded(images, partition="lpt", dst=0, n_fields=None, output=
             del held[i]
         if mine:
             share = load(mine)
-            wide_local = int(share.dtype != np.float16 and share.size > 0 and float(share.max()) > 65535)
+            wide_local = int(share.dtype == np.uint32 or (share.dtype != np.float16 and share.size > 0 and float(share.max()) > 65535))
         held.clear()
     except Exception as e:      # noqa: BLE001
         err = e

@@ -59,7 +59,8 @@ def as_u16_fields(image):
 
 def as_pixel_fields(image, wide=False):
     """-> (pixel words to upload, pixel format).  Integer images (and floats, truncated toward zero) whose values fit 16 bits
-    become uint16 words; with a value beyond 65 535 - or with wide=True - uint32 words (PIXELS_U32, values below 2^31); a
+    become uint16 words; with a value beyond 65 535 - or with wide=True, or handed over as uint32 - uint32 words (PIXELS_U32, values
+    below 2^31); a
     float16 image (BASELINE.json configs[4]: pixel values pre-scaled into binary16) is uploaded as it is and truncated toward zero
     by the kernels' loads, which is what the reference's image.astype(np.int64) (pflib.py:241, 443) does with it."""
     a = np.asarray(image)
@@ -71,6 +72,11 @@ def as_pixel_fields(image, wide=False):
         if a.size and not np.isfinite(a).all():
             raise NotImplementedError("non-finite pixel values are not supported by the GPU path")
         a = a.astype(np.int64)                      # truncation toward zero, as the reference
+    if a.dtype == np.uint32:
+        # uint32 input is taken as it is - no pass over the data to see whether it would fit 16 bits, no copy (a stack of 1 024
+        # fields is 1 GB: each pass costs 0.1 s of a 0.4 s call); values of 2^31 and more are refused where the data is next touched
+        # (pflib: the stager's per-chunk maximum / _pixel_max)
+        return np.ascontiguousarray(a), N.PIXELS_U32
     if wide and a.dtype.kind in "iub" and a.dtype != np.float16:      # (the caller wants uint32 words whatever the values are)
         if a.size and (int(a.min()) < 0 or int(a.max()) >= 2 ** 31):
             raise NotImplementedError("pixel values outside [0, 2^31) are not supported by the GPU path")
@@ -87,7 +93,10 @@ def as_integer_fields(image):
     """-> (pixel words, PIXELS_U16 or PIXELS_U32) for the entry points that read VALUES only (photometry, centroid tracking): like
     as_pixel_fields, but a float16 image is truncated to integers like any other float image instead of being uploaded as binary16 words."""
     a = np.asarray(image)
-    return as_pixel_fields(a.astype(np.float32) if a.dtype == np.float16 else a)
+    words, fmt = as_pixel_fields(a.astype(np.float32) if a.dtype == np.float16 else a)
+    if fmt == N.PIXELS_U32 and words.size and int(words.max()) >= 2 ** 31:         # (uint32 input is not scanned by as_pixel_fields)
+        raise NotImplementedError("pixel values outside [0, 2^31) are not supported by the GPU path")
+    return words, fmt
 
 
 def quantise_f16(images):

@@ -73,7 +73,21 @@ def _device_key():
 
 def _pixel_max(words, fmt):
     """Largest pixel value of a PIXELS_U32 stack (bounds the detection's integer domain); None for the 16-bit formats."""
-    return int(words.max()) if (fmt == N.PIXELS_U32 and words.size) else None
+    if fmt != N.PIXELS_U32 or not words.size:
+        return None
+    vmax = int(words.max())
+    if vmax >= 2 ** 31:
+        raise NotImplementedError("pixel values outside [0, 2^31) are not supported by the GPU path")
+    return vmax
+
+
+def _chunk_params(prm, host_words):
+    """The detection parameters of ONE chunk of a PIXELS_U32 stack: a copy of `prm` with pixel_bits from the chunk's own maximum
+    (taken by the stager thread on the words it has just copied - the only pass over the pixels the host makes)."""
+    vmax = _pixel_max(host_words, N.PIXELS_U32)
+    out = N.FsqDetectParams.from_buffer_copy(prm)
+    out.pixel_bits = max(1, int(vmax).bit_length())
+    return out
 
 
 def _psf_candidates(image, median_filter_size=5, correlation_matrix=default_correlation_matrix, c_std=2, **kwargs):
@@ -439,7 +453,7 @@ class _BatchRunner:
                                 if isinstance(item, BaseException):
                                     raise item
                                 return
-                            c, i = item
+                            c, i, prm_c = item
                             d = self.pin[i][:sizes[c]].to(self.dev, non_blocking=True)
                             self.pin_ev[i] = torch.cuda.Event()
                             self.pin_ev[i].record()
@@ -447,7 +461,7 @@ class _BatchRunner:
                             # the whole path of the chunk as one library call (no interpreter between the stages: the
                             # worker that builds the dicts has it); the runner's buffers are re-used, so what the worker
                             # will copy to the host is cloned
-                            rec, offs, nk, _ = eng.run(d, prm, r_2_threshold, radius, self.mode, PY2_ROUND)
+                            rec, offs, nk, _ = eng.run(d, prm_c, r_2_threshold, radius, self.mode, PY2_ROUND)
                             # records and counts go to pinned host buffers on this lane's stream right away (the runner's
                             # device buffers are free for its next chunk, stream order); the worker only waits for the event
                             m, kk = sizes[c], int(rec.shape[0])
@@ -501,7 +515,8 @@ class _BatchRunner:
                     host[:len(part)] = part
                     if len(part) < per and n_lanes == 0:    # (pipeline engines have a fixed field count: the last chunk is filled up with copies of its last field)
                         host[len(part):] = part[-1]
-                    if not put_staged((c, i) if n_lanes > 0 else i):
+                    prm_c = _chunk_params(prm, host[:len(part)]) if self.wide else prm
+                    if not put_staged((c, i, prm_c) if n_lanes > 0 else (i, prm_c)):
                         return
                 if n_lanes > 0:
                     put_staged(None)
@@ -510,14 +525,15 @@ class _BatchRunner:
 
         def jobs():
             for c in range(n_chunks):
-                i = staged.get()
-                if isinstance(i, BaseException):
-                    raise i
+                item = staged.get()
+                if isinstance(item, BaseException):
+                    raise item
+                i, prm_c = item
                 bufs[c] = self.pin[i].to(self.dev, non_blocking=True)
                 self.pin_ev[i] = torch.cuda.Event()
                 self.pin_ev[i].record()
                 self.pin_free[i].set()
-                yield bufs[c], prm
+                yield bufs[c], prm_c
 
         def materialise(c, rec, offs, nk, ev):
             with torch.cuda.device(self.dev):
@@ -646,7 +662,7 @@ def find_peptides_batch(images, median_filter_size=5, correlation_matrix=default
                                   "(pflib.py:117-177) and is not reproduced")
     # (candidate_pixels: "Not yet implemented" in the reference, pflib.py:374 - accepted and ignored there and here)
     imgs, fmt = _engine.as_pixel_fields(images)            # integer dtypes, floats holding integer values, or float16
-    prm = _engine.detect_params(median_filter_size, correlation_matrix, c_std, fmt, _pixel_max(imgs, fmt))
+    prm = _engine.detect_params(median_filter_size, correlation_matrix, c_std, fmt)   # (PIXELS_U32: pixel_bits per chunk / small pass)
     if imgs.ndim != 3:
         raise ValueError("images must have shape (n, H, W)")
     n, H, W = imgs.shape
@@ -658,14 +674,14 @@ def find_peptides_batch(images, median_filter_size=5, correlation_matrix=default
     if wide and mode == N.MODE_TEXTBOOK_F32:
         raise NotImplementedError("solver='textbook_f32' takes 16-bit pixels only")
     if wide and engine is not None:
-        out = _wide_pass(engine, imgs, prm, r_2_threshold, consolidation_radius, mode)
+        out = _wide_pass(engine, imgs, _chunk_params(prm, imgs), r_2_threshold, consolidation_radius, mode)
     elif engine is not None:                                # (a caller-owned Engine: one stand-alone pass)
         d_img = _engine.to_device_u16(imgs)
         engine.run(d_img, prm, r_2_threshold, consolidation_radius, mode, PY2_ROUND)
         out = _engine_dicts(engine, d_img, fmt)
     elif (n * H * W <= min(SMALL_PASS_PIXELS, CHUNK_PIXELS) and mode != N.MODE_TEXTBOOK_F32
           and "FSQ_BATCH_LANES" not in os.environ):            # (one chunk, and a small one)
-        out = _small_pass(imgs, fmt, prm, r_2_threshold, consolidation_radius, mode)
+        out = _small_pass(imgs, fmt, _chunk_params(prm, imgs) if wide else prm, r_2_threshold, consolidation_radius, mode)
         if on_chunk is not None:
             on_chunk(0, out)
     else:
@@ -698,7 +714,7 @@ def find_peptides_records(images, median_filter_size=5, correlation_matrix=defau
     is_wide = fmt == N.PIXELS_U32
     if is_wide and mode == N.MODE_TEXTBOOK_F32:
         raise NotImplementedError("solver='textbook_f32' takes 16-bit pixels only")
-    prm = _engine.detect_params(median_filter_size, correlation_matrix, c_std, fmt, _pixel_max(imgs, fmt))
+    prm = _engine.detect_params(median_filter_size, correlation_matrix, c_std, fmt)        # (PIXELS_U32: pixel_bits per chunk)
     if imgs.ndim != 3:
         raise ValueError("images must have shape (n, H, W)")
     n, H, W = imgs.shape

@@ -183,13 +183,22 @@ def test_every_fit_equals_oracle(env):
 
 
 def test_small_values_in_wide_dtypes_take_the_16_bit_path(env):
-    """A uint32 / int64 / float64 array whose values fit 16 bits is the same image as its uint16 copy."""
+    """An int64 / float64 array whose values fit 16 bits is the same image as its uint16 copy and takes the 16-bit route; a uint32
+    array is taken as it is (no pass over a possibly huge stack to find out) and gives the same results on the 32-bit route."""
     torch, N, E, pflib, synth, O = env
     img = synth.make_field(9, (128, 128), 20)
     ref = pflib.find_peptides(img)
-    for dt in (np.uint32, np.int64, np.float64):
+    for dt in (np.int64, np.float64):
         words, fmt = E.as_pixel_fields(img.astype(dt))
         assert fmt == N.PIXELS_U16 and words.dtype == np.uint16
+    u32 = img.astype(np.uint32)
+    words, fmt = E.as_pixel_fields(u32)
+    assert fmt == N.PIXELS_U32 and words is u32
+    for bad in (np.full((16, 16), 2 ** 31, np.uint32), np.full((3, 16, 16), 2 ** 32 - 1, np.uint32)):
+        with pytest.raises(NotImplementedError):
+            (pflib.find_peptides if bad.ndim == 2 else pflib.find_peptides_batch)(bad)
+    with pytest.raises(NotImplementedError):
+        E.as_integer_fields(np.full((16, 16), 2 ** 31, np.uint32))
     words, fmt = E.as_pixel_fields(img.astype(np.int64) * 1000)
     assert fmt == N.PIXELS_U32 and words.dtype == np.uint32
     words, fmt = E.as_pixel_fields(img.astype(np.float64) * 1000.5)
